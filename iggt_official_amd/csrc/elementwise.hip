@@ -1,0 +1,298 @@
+// HBM-bound fused elementwise / normalisation kernels of the IGGT aggregator.
+// All loads/stores are 8- or 16-byte vectors, one wave (or 8-lane group) per reduction row, no LDS.
+#include "common.h"
+#include "../../include/iggt_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim, fp32 in -> bf16 out (the A operand of the following GEMM).
+// Reference: nn.LayerNorm norm1/norm2 in iggt/layers/block.py:41,50,67,84,87 (eps 1e-5 in the
+// aggregator blocks, 1e-6 in the DINOv2 blocks, vision_transformer.py:94), final DINOv2 norm
+// (vision_transformer.py:274), DPT token norm on the concatenated [frame|global] halves
+// (iggt/heads/dpt_head.py:232).  Under the reference's autocast, LayerNorm runs in fp32 and the
+// consumer Linear rounds its input to bf16: same rounding point as here.
+//
+// One wave per row; NV float4 per lane; two-pass (mean, then centred variance) in registers.
+// Input may be the concatenation of two row-major matrices (x0 | x1), each C/2 wide, and input rows
+// may be remapped (skip the 5 special tokens of each view).
+struct LnParams {
+    const float* x0;
+    const float* x1;  // null: single source of width C
+    long ld0, ld1;
+    const float* w;
+    const float* b;
+    bf16_t* out;
+    long ldo;
+    float* out_f32;  // optional fp32 output instead of bf16
+    int rows;
+    float eps;
+    int rows_in, rows_stride, row_off;  // in_row = (r / rows_in) * rows_stride + row_off + r % rows_in
+    int orows_stride, orow_off;         // out_row likewise (orows_stride == 0: out_row = r)
+};
+
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
+    constexpr int C = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    long irow = row, orow = row;
+    if (p.rows_in > 0) {
+        const int g = row / p.rows_in;
+        irow = (long)g * p.rows_stride + p.row_off + (row - g * p.rows_in);
+        if (p.orows_stride > 0) orow = (long)g * p.orows_stride + p.orow_off + (row - g * p.rows_in);
+    }
+    f32x4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int col = j * 256 + lane * 4;
+        const float* src;
+        if (p.x1 != nullptr && j >= NV / 2) src = p.x1 + irow * p.ld1 + (col - C / 2);
+        else src = p.x0 + irow * p.ld0 + col;
+        v[j] = *reinterpret_cast<const f32x4*>(src);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    const float mean = wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[j][e] - mean;
+            q += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + p.eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int col = j * 256 + lane * 4;
+        const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + col);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b + col);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (v[j][e] - mean) * rstd * w[e] + bb[e];
+        if (p.out_f32) {
+            *reinterpret_cast<f32x4*>(p.out_f32 + orow * p.ldo + col) = y;
+        } else {
+            u32x2 o;
+            o[0] = pack_bf16x2(y[0], y[1]);
+            o[1] = pack_bf16x2(y[2], y[3]);
+            *reinterpret_cast<u32x2*>(p.out + orow * p.ldo + col) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-head LayerNorm(64) on q and k followed by 2-D RoPE; optional copy of v.
+// Reference: iggt/layers/attention.py:54-58 (q_norm/k_norm then rope) and
+// iggt/layers/rope.py:119-188.  Head dim 64 = [y-half 32 | x-half 32]; within a half the
+// rotation pairs element i with i+16 and angle index i%16:
+//     out[i] = t[i]*cos(th_{i%16}) + (i<16 ? -t[i+16] : t[i-16]) * sin(th_{i%16}),  th_f = pos * 100^(-f/16)
+// cos/sin come from a host-built fp32 table [max_pos+1][16] (same values torch computes in the
+// reference's frequency cache, rope.py:100-117).  Token p of a view: p < patch_start -> pos (0,0)
+// (identity), else (y,x) = ((p-ps)/gw + 1, (p-ps)%gw + 1)  (aggregator.py:236-245).
+//
+// One block (256 threads) per token: thread -> (which = q|k, head, 8-element slice j); the 8 lanes
+// of a head reduce with xor-shuffles 1,2,4; the RoPE partner slice is lane^2.
+struct QkParams {
+    const bf16_t* qkv;  // [T][3*C]
+    long ld_in;
+    bf16_t* q_out; long ldq;
+    bf16_t* k_out; long ldk;
+    bf16_t* v_out; long ldv;  // optional
+    const float* qw; const float* qb; const float* kw; const float* kb;  // [64] each
+    const float* cos_t; const float* sin_t;  // [npos][16]
+    int T, P, gw, patch_start;
+    float eps;
+    int C;  // 1024
+};
+
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
+    const int t = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int which = tid >> 7, head = (tid >> 3) & 15, j = tid & 7;
+    const bf16_t* src = p.qkv + (long)t * p.ld_in + which * p.C + head * 64 + j * 8;
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(src);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        x[2 * e] = bf16_lo(raw[e]);
+        x[2 * e + 1] = bf16_hi(raw[e]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += x[e];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    const float mean = s * (1.0f / 64);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = x[e] - mean; q += d * d; }
+    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+    const float rstd = rsqrtf(q * (1.0f / 64) + p.eps);
+    const float* w = which ? p.kw : p.qw;
+    const float* bb = which ? p.kb : p.qb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (x[e] - mean) * rstd * w[j * 8 + e] + bb[j * 8 + e];
+
+    // RoPE
+    const int pt = t % p.P;
+    int py = 0, px = 0;
+    if (pt >= p.patch_start) {
+        const int idx = pt - p.patch_start;
+        py = idx / p.gw + 1;
+        px = idx - (py - 1) * p.gw + 1;
+    }
+    const int pos = (j < 4) ? py : px;
+    const int f0 = (j & 1) * 8;
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float partner = __shfl_xor(x[e], 2, 64);
+        const float rot = (j & 2) ? partner : -partner;
+        const float cs = p.cos_t[pos * 16 + f0 + e], sn = p.sin_t[pos * 16 + f0 + e];
+        y[e] = x[e] * cs + rot * sn;
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(y[2 * e], y[2 * e + 1]);
+    bf16_t* dst = which ? (p.k_out + (long)t * p.ldk) : (p.q_out + (long)t * p.ldq);
+    *reinterpret_cast<u32x4*>(dst + head * 64 + j * 8) = o;
+
+    if (p.v_out != nullptr && tid < 128) {  // copy v: 1024 bf16 = 128 x 16 B
+        const u32x4 vv = *reinterpret_cast<const u32x4*>(p.qkv + (long)t * p.ld_in + 2 * p.C + tid * 8);
+        *reinterpret_cast<u32x4*>(p.v_out + (long)t * p.ldv + tid * 8) = vv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// im2row for the 14x14/14 patch-embed conv, fused with the ImageNet normalisation.
+// Reference: (images - mean)/std at iggt/models/aggregator.py:206; Conv2d(3,1024,14,14) at
+// iggt/layers/patch_embed.py:62,75-77.  Row (s, gy, gx) of the output holds the 588 = 3*14*14 taps in
+// the conv-weight order (c, ky, kx), zero-padded to Kpad (multiple of 64) -> bf16 A operand.
+struct Im2rowParams {
+    const float* img;  // [S][3][H][W] in [0,1]
+    bf16_t* out;       // [S*gh*gw][Kpad]
+    int S, H, W, gh, gw, Kpad;
+};
+
+__global__ __launch_bounds__(256) void im2row_patch14_kernel(const Im2rowParams p) {
+    const long total = (long)p.S * p.gh * p.gw * (p.Kpad / 2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int kp = (int)(i % (p.Kpad / 2));
+        const long row = i / (p.Kpad / 2);
+        const int gx = (int)(row % p.gw);
+        const int gy = (int)((row / p.gw) % p.gh);
+        const int s = (int)(row / ((long)p.gw * p.gh));
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = kp * 2 + e;
+            if (k < 588) {
+                const int c = k / 196, r = k - c * 196, ky = r / 14, kx = r - ky * 14;
+                const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
+                const float stdv = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+                const float px = p.img[(((long)s * 3 + c) * p.H + gy * 14 + ky) * p.W + gx * 14 + kx];
+                v[e] = (px - mean) / stdv;
+            } else {
+                v[e] = 0.f;
+            }
+        }
+        *reinterpret_cast<uint32_t*>(p.out + row * p.Kpad + kp * 2) = pack_bf16x2(v[0], v[1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Broadcast "special" token rows into a [S][P][C] fp32 token matrix:
+//   dst[s][row_off + r][:] = (s == 0 ? src0 : src1)[r][:]   for r < nrows
+// Reference: cls/register insertion (vision_transformer.py:222-234, src0 == src1) and
+// camera/register tokens with the view-0 / other-views split (aggregator.py:230-234,338-361).
+struct SpecialParams {
+    float* dst; long view_stride; long ldd;
+    const float* src0; const float* src1;
+    int S, nrows, row_off, C, first_view_is_zero;
+};
+
+__global__ __launch_bounds__(256) void write_special_tokens_kernel(const SpecialParams p) {
+    const int per_view = p.nrows * (p.C / 4);
+    const long total = (long)p.S * per_view;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(i / per_view);
+        const int rem = (int)(i - (long)s * per_view);
+        const int r = rem / (p.C / 4), c4 = rem - r * (p.C / 4);
+        const float* src = (s == 0 && p.first_view_is_zero) ? p.src0 : p.src1;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)r * p.C + c4 * 4);
+        *reinterpret_cast<f32x4*>(p.dst + (long)s * p.view_stride + (long)(p.row_off + r) * p.ldd + c4 * 4) = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int iggt_layernorm_f32(const float* x0, long ld0, const float* x1, long ld1, const float* w,
+                                  const float* b, void* out, long ldo, int out_is_f32, int rows, int C,
+                                  float eps, int rows_in, int rows_stride, int row_off, int orows_stride, int orow_off,
+                                  void* stream) {
+    if (rows <= 0) return -1;
+    if ((ld0 % 4) || (x1 && (ld1 % 4)) || (ldo % 4)) return -2;
+    LnParams p;
+    p.x0 = x0; p.x1 = x1; p.ld0 = ld0; p.ld1 = ld1; p.w = w; p.b = b;
+    p.out = out_is_f32 ? nullptr : (bf16_t*)out;
+    p.out_f32 = out_is_f32 ? (float*)out : nullptr;
+    p.ldo = ldo; p.rows = rows; p.eps = eps;
+    p.rows_in = rows_in; p.rows_stride = rows_stride; p.row_off = row_off;
+    p.orows_stride = orows_stride; p.orow_off = orow_off;
+    const dim3 grid((rows + 3) / 4), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, p);
+    else if (C == 2048) hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, st, p);
+    else if (C == 256 && !x1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, p);
+    else if (C == 512 && !x1) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, p);
+    else return -3;
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int iggt_qknorm_rope_bf16(const void* qkv, long ld_in, void* q_out, long ldq, void* k_out, long ldk,
+                                     void* v_out, long ldv, const float* qw, const float* qb, const float* kw,
+                                     const float* kb, const float* cos_t, const float* sin_t, int T, int P,
+                                     int gw, int patch_start, float eps, void* stream) {
+    if (T <= 0 || P <= 0) return -1;
+    if ((ld_in % 8) || (ldq % 8) || (ldk % 8) || (v_out && (ldv % 8))) return -2;
+    QkParams p;
+    p.qkv = (const bf16_t*)qkv; p.ld_in = ld_in;
+    p.q_out = (bf16_t*)q_out; p.ldq = ldq; p.k_out = (bf16_t*)k_out; p.ldk = ldk;
+    p.v_out = (bf16_t*)v_out; p.ldv = ldv;
+    p.qw = qw; p.qb = qb; p.kw = kw; p.kb = kb; p.cos_t = cos_t; p.sin_t = sin_t;
+    p.T = T; p.P = P; p.gw = gw; p.patch_start = patch_start; p.eps = eps; p.C = 1024;
+    hipLaunchKernelGGL(qknorm_rope_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, p);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int iggt_im2row_patch14(const float* img, void* out, int S, int H, int W, int Kpad, void* stream) {
+    if (S <= 0 || (H % 14) || (W % 14) || Kpad < 588 || (Kpad % 64)) return -1;
+    Im2rowParams p;
+    p.img = img; p.out = (bf16_t*)out; p.S = S; p.H = H; p.W = W; p.gh = H / 14; p.gw = W / 14; p.Kpad = Kpad;
+    const long total = (long)S * p.gh * p.gw * (Kpad / 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(im2row_patch14_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int iggt_write_special_tokens(float* dst, long view_stride, long ldd, const float* src0,
+                                         const float* src1, int S, int nrows, int row_off, int C,
+                                         int first_view_is_zero, void* stream) {
+    if (S <= 0 || nrows <= 0 || (C % 4) || (ldd % 4) || (view_stride % 4)) return -1;
+    SpecialParams p;
+    p.dst = dst; p.view_stride = view_stride; p.ldd = ldd; p.src0 = src0; p.src1 = src1;
+    p.S = S; p.nrows = nrows; p.row_off = row_off; p.C = C; p.first_view_is_zero = first_view_is_zero;
+    const long total = (long)S * nrows * (C / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(write_special_tokens_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}

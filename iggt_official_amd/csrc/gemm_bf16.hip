@@ -1,0 +1,195 @@
+// bf16 MFMA GEMM with fused epilogues for the IGGT linear layers.
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]        A: [M,K] bf16 row-major (lda), W: [N,K] bf16 (ldw)
+//
+// W is in torch.nn.Linear layout ([out,in]), so both MFMA operands are read along K ("B^T
+// input"), each lane taking 8 contiguous bf16 (16 B) of one row.  fp32 accumulation.
+//
+// Replaces on the hot path (reference file:line):
+//   attn.qkv / attn.proj            iggt/layers/attention.py:40,45,52,75
+//   mlp.fc1 + GELU / mlp.fc2        iggt/layers/mlp.py:34-39
+//   LayerScale + residual add       iggt/layers/layer_scale.py:26, iggt/layers/block.py:105-106
+//   patch-embed conv (as im2row GEMM) + pos-embed add   iggt/layers/patch_embed.py:75-77,
+//                                                       iggt/layers/vision_transformer.py:223
+//
+// Tile: 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_bf16.
+// Global->register->LDS staging, issued one K-tile ahead and written after the MFMA phase
+// (split issue/write), double-buffered LDS (64 KiB -> 2 workgroups/CU), XOR-swizzled rows
+// (common.h swz_off) so the ds_read_b128 operand reads are bank-conflict free.
+// Grid: 1-D over (m-tile, n-tile), n fastest, XCD-chunked so one XCD's L2 keeps the A row-panel.
+#include "common.h"
+#include "../../include/iggt_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per buffer
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* W;
+    int M, N, K;
+    long lda, ldw;
+    int tiles_n;
+    // epilogue
+    const float* bias;       // [N] or null
+    const float* gamma;      // [N] or null
+    const float* add_table;  // [rows_in][N] fp32 or null, indexed by (m % rows_in)
+    float* out_f32;          // exactly one of out_f32 / out_bf16
+    bf16_t* out_bf16;
+    long ldo;
+    int accumulate;  // out_f32 += value
+    int act;         // 0 none, 1 exact GELU, 2 ReLU
+    int rows_in, rows_out, row_off;  // output row remap (rows_in == 0: identity)
+};
+
+IGGT_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = v / p.tiles_n, tn = v - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging map: thread -> (row = tid/8 + 32*i, 16-B piece = tid%8) -------------------------
+    const int ld_row = tid >> 3, ld_piece = tid & 7;
+    const bf16_t* a_src[4];
+    const bf16_t* w_src[4];
+    int lds_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ld_row + 32 * i;
+        int ra = m0 + r;
+        ra = ra < p.M ? ra : p.M - 1;  // tail rows: duplicate the last row, masked at the store
+        int rw = n0 + r;
+        rw = rw < p.N ? rw : p.N - 1;
+        a_src[i] = p.A + (long)ra * p.lda + ld_piece * 8;
+        w_src[i] = p.W + (long)rw * p.ldw + ld_piece * 8;
+        lds_off[i] = swz_off(r, ld_piece);
+    }
+    u32x4 sa[4], sw[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sa[i] = *reinterpret_cast<const u32x4*>(a_src[i] + kt * BK);
+            sw[i] = *reinterpret_cast<const u32x4*>(w_src[i] + kt * BK);
+        }
+    };
+    auto swrite = [&](int buf) {
+        char* sA = smem + buf * (2 * TILE_BYTES);
+        char* sW = sA + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(sA + lds_off[i]) = sa[i];
+            *reinterpret_cast<u32x4*>(sW + lds_off[i]) = sw[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // operand read offsets: row = base + (lane&31); slot = 2*kc + (lane>>5); key = (row>>1)&7
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int KT = p.K / BK;
+
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) gload(kt + 1);
+        const char* sA = smem + (kt & 1) * (2 * TILE_BYTES);
+        const char* sW = sA + TILE_BYTES;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                a[i] = *reinterpret_cast<const bf16x8*>(sA + swz_off(wm * 64 + i * 32 + frow, 2 * kc + fhalf));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                b[j] = *reinterpret_cast<const bf16x8*>(sW + swz_off(wn * 64 + j * 32 + frow, 2 * kc + fhalf));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+        }
+        if (kt + 1 < KT) swrite((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        const float gamma = p.gamma ? p.gamma[n] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
+                if (m >= p.M) continue;
+                float val = acc[i][j][r] + bias;
+                if (p.act == 1) val = gelu_erf(val);
+                else if (p.act == 2) val = fmaxf(val, 0.f);
+                val *= gamma;
+                long orow = m;
+                if (p.rows_in > 0) {
+                    const int g = m / p.rows_in, w = m - g * p.rows_in;
+                    orow = (long)g * p.rows_out + p.row_off + w;
+                    if (p.add_table) val += p.add_table[(long)w * p.N + n];
+                }
+                if (p.out_f32) {
+                    float* dst = p.out_f32 + orow * p.ldo + n;
+                    *dst = p.accumulate ? (*dst + val) : val;
+                } else {
+                    p.out_bf16[orow * p.ldo + n] = (bf16_t)val;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int iggt_gemm_bf16(const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+                              const float* bias, const float* gamma, const float* add_table,
+                              void* out, long ldo, int out_is_f32, int accumulate, int act,
+                              int rows_in, int rows_out, int row_off, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0) return -1;
+    if ((lda % 8) != 0 || (ldw % 8) != 0) return -2;  // 16-B aligned operand rows
+    if (accumulate && !out_is_f32) return -3;
+    if (add_table && rows_in <= 0) return -4;
+    GemmParams p;
+    p.A = (const bf16_t*)A;
+    p.W = (const bf16_t*)W;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.ldw = ldw;
+    p.tiles_n = (N + BN - 1) / BN;
+    p.bias = bias; p.gamma = gamma; p.add_table = add_table;
+    p.out_f32 = out_is_f32 ? (float*)out : nullptr;
+    p.out_bf16 = out_is_f32 ? nullptr : (bf16_t*)out;
+    p.ldo = ldo;
+    p.accumulate = accumulate; p.act = act;
+    p.rows_in = rows_in; p.rows_out = rows_out; p.row_off = row_off;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int lds = 2 * 2 * TILE_BYTES;  // 64 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tiles_m * p.tiles_n), dim3(256), lds, (hipStream_t)stream, p);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,217 @@
+"""DPT dense-prediction head (depth / point maps) -- reference iggt/heads/dpt_head.py:21-509.
+
+State-dict layout is the reference's (`norm`, `projects.{0..3}`, `resize_layers.{0,1,3}`,
+`scratch.layer{1..4}_rn`, `scratch.refinenet{1..4}.{out_conv,resConfUnit{1,2}.conv{1,2}}`,
+`scratch.output_conv1`, `scratch.output_conv2.{0,2}`).
+
+Execution on the MI355X (round 1 state):
+  * token stage in HIP: LayerNorm(2048) over the [frame|global] token halves with the 5 special
+    tokens skipped by row remap, then the 1x1 "projects" conv as a bf16 MFMA GEMM whose epilogue adds
+    the bias and the (input-independent, cached) UV sin/cos position map -- one pass, NHWC output;
+  * the convolutional pyramid (3x3 / transposed convs, bilinear align_corners resizes) runs through
+    PyTorch-ROCm (MIOpen) in fp32 exactly as the reference does under `autocast(enabled=False)`
+    (vggt.py:189); DESIGN.md lists it as the next kernel family to move to hand-written HIP.
+Frames are independent in every head op (BatchNorm-free, per-frame convs: SURVEY.md section 0
+fact 6), so `frames_chunk_size` only bounds memory; the result is identical for any chunking
+(the reference's own chunked branch is broken for S > 12, appendix D.1).
+"""
+from typing import List, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _C
+from ..layers.blocks import Workspace
+from .head_act import activate_head
+from .utils import pos_embed_map, pos_embed_xy
+
+
+def custom_interpolate(x, size=None, scale_factor=None, mode="bilinear", align_corners=True):
+    if size is None:
+        size = (int(x.shape[-2] * scale_factor), int(x.shape[-1] * scale_factor))
+    return F.interpolate(x, size=size, mode=mode, align_corners=align_corners)
+
+
+class ResidualConvUnit(nn.Module):
+    """conv2(relu(conv1(relu(x)))) + relu(x): the skip adds the *rectified* input because the
+    reference's activation is nn.ReLU(inplace=True) (dpt_head.py:327,401,411)."""
+
+    def __init__(self, features, activation=None, bn=False, groups=1):
+        super().__init__()
+        self.bn, self.groups = bn, groups
+        self.conv1 = nn.Conv2d(features, features, 3, 1, 1, bias=True, groups=groups)
+        self.conv2 = nn.Conv2d(features, features, 3, 1, 1, bias=True, groups=groups)
+        self.norm1 = None
+        self.norm2 = None
+
+    def forward(self, x):
+        r = F.relu(x)
+        return self.conv2(F.relu(self.conv1(r))) + r
+
+
+class FeatureFusionBlock(nn.Module):
+    def __init__(self, features, activation=None, deconv=False, bn=False, expand=False, align_corners=True,
+                 size=None, has_residual=True, groups=1):
+        super().__init__()
+        self.align_corners = align_corners
+        self.out_conv = nn.Conv2d(features, features // 2 if expand else features, 1, 1, 0, bias=True,
+                                  groups=groups)
+        if has_residual:
+            self.resConfUnit1 = ResidualConvUnit(features, activation, bn, groups=groups)
+        self.has_residual = has_residual
+        self.resConfUnit2 = ResidualConvUnit(features, activation, bn, groups=groups)
+        self.size = size
+
+    def forward(self, *xs, size=None):
+        y = xs[0]
+        if self.has_residual:
+            y = y + self.resConfUnit1(xs[1])
+        y = self.resConfUnit2(y)
+        if size is None and self.size is None:
+            y = custom_interpolate(y, scale_factor=2, align_corners=self.align_corners)
+        else:
+            y = custom_interpolate(y, size=size if size is not None else self.size,
+                                   align_corners=self.align_corners)
+        return self.out_conv(y)
+
+
+def _make_fusion_block(features, size=None, has_residual=True, groups=1):
+    return FeatureFusionBlock(features, None, deconv=False, bn=False, expand=False, align_corners=True,
+                              size=size, has_residual=has_residual, groups=groups)
+
+
+def _make_scratch(in_shape, out_shape, groups=1, expand=False):
+    scratch = nn.Module()
+    outs = [out_shape * (2 ** i if expand else 1) for i in range(4)]
+    for i, cin in enumerate(in_shape[:4]):
+        setattr(scratch, f"layer{i + 1}_rn", nn.Conv2d(cin, outs[i], 3, 1, 1, bias=False, groups=groups))
+    return scratch
+
+
+class TokenProjector:
+    """LayerNorm(2C) + 1x1 conv on patch tokens, in HIP.  Shared by DPTHead and the adaptors."""
+
+    def __init__(self):
+        self.ws = Workspace()
+        self._pk = {}
+
+    def packed(self, idx, conv: nn.Conv2d):
+        w = conv.weight
+        key = (w.data_ptr(), w._version)
+        if self._pk.get(idx, (None,))[0] != key:
+            self._pk[idx] = (key, w.detach().reshape(w.shape[0], -1).to(torch.bfloat16).contiguous(),
+                             conv.bias.detach().float().contiguous())
+        return self._pk[idx][1:]
+
+    def __call__(self, tokens, s0, s1, psi, gh, gw, norm: nn.LayerNorm, idx, conv: nn.Conv2d, pos_table=None):
+        """tokens [1, S_all, P, 2C] fp32 -> NCHW-viewed (channels-last memory) [S, oc, gh, gw] fp32."""
+        if not tokens.is_cuda:
+            raise _C.HipExtensionError("head token projection runs on HIP kernels only")
+        _, S_all, P, C2 = tokens.shape
+        S, g2 = s1 - s0, gh * gw
+        t = tokens[0, s0:s1]
+        assert t.is_contiguous() and P == psi + g2
+        xn = self.ws.get("xn", (S * g2, C2), torch.bfloat16, tokens.device)
+        _C.layernorm(t.reshape(S * P, C2), norm.weight.detach().float(), norm.bias.detach().float(), xn,
+                     norm.eps, rows=S * g2, rows_in=g2, rows_stride=P, row_off=psi)
+        w, b = self.packed(idx, conv)
+        out = torch.empty(S * g2, w.shape[0], dtype=torch.float32, device=tokens.device)
+        _C.gemm_bf16(xn, w, out, bias=b, add_table=pos_table, rows_in=g2, rows_out=g2, row_off=0)
+        return out.view(S, gh, gw, w.shape[0]).permute(0, 3, 1, 2)
+
+
+class DPTHead(nn.Module):
+    def __init__(self, dim_in, patch_size=14, output_dim=4, activation="inv_log", conf_activation="expp1",
+                 features=256, out_channels=[256, 512, 1024, 1024], intermediate_layer_idx=[4, 11, 17, 23],
+                 pos_embed=True, use_point_feat=False, down_ratio=1, for_tracker=False):
+        super().__init__()
+        self.patch_size = patch_size
+        self.activation = activation
+        self.conf_activation = conf_activation
+        self.pos_embed = pos_embed
+        self.for_tracker = for_tracker
+        self.use_point_feat = use_point_feat
+        self.down_ratio = down_ratio
+        self.intermediate_layer_idx = intermediate_layer_idx
+        self.norm = nn.LayerNorm(dim_in)
+        self.projects = nn.ModuleList([nn.Conv2d(dim_in, oc, 1, 1, 0) for oc in out_channels])
+        self.resize_layers = nn.ModuleList([
+            nn.ConvTranspose2d(out_channels[0], out_channels[0], 4, 4, 0),
+            nn.ConvTranspose2d(out_channels[1], out_channels[1], 2, 2, 0),
+            nn.Identity(),
+            nn.Conv2d(out_channels[3], out_channels[3], 3, 2, 1),
+        ])
+        self.scratch = _make_scratch(out_channels, features, expand=False)
+        self.scratch.stem_transpose = None
+        self.scratch.refinenet1 = _make_fusion_block(features)
+        self.scratch.refinenet2 = _make_fusion_block(features)
+        self.scratch.refinenet3 = _make_fusion_block(features)
+        self.scratch.refinenet4 = _make_fusion_block(features, has_residual=False)
+        h1, h2 = features, 32
+        if for_tracker:
+            self.scratch.output_conv1 = nn.Conv2d(h1, h1, 3, 1, 1)
+        else:
+            self.scratch.output_conv1 = nn.Conv2d(h1, h1 // 2, 3, 1, 1)
+            self.scratch.output_conv2 = nn.Sequential(nn.Conv2d(h1 // 2, h2, 3, 1, 1), nn.ReLU(inplace=True),
+                                                      nn.Conv2d(h2, output_dim, 1, 1, 0))
+        self._tp = TokenProjector()
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, aggregated_tokens_list, images, patch_start_idx, frames_chunk_size=8):
+        B, S, _, H, W = images.shape
+        if B != 1:
+            raise NotImplementedError("heads run one scene (B=1) at a time, as demo.py does")
+        chunk = S if (frames_chunk_size is None or frames_chunk_size >= S) else frames_chunk_size
+        assert chunk > 0
+        parts = [self._forward_impl(aggregated_tokens_list, images, patch_start_idx, s0, min(s0 + chunk, S))
+                 for s0 in range(0, S, chunk)]
+        if len(parts) == 1:
+            return parts[0]
+        if self.for_tracker:
+            return torch.cat(parts, dim=1)
+        merged = [torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1)]
+        if self.use_point_feat:
+            merged.append(tuple(torch.cat([p[2][i] for p in parts], 0) for i in range(3)))
+        return tuple(merged)
+
+    def _token_maps(self, tokens_list, psi, s0, s1, H, W):
+        gh, gw = H // self.patch_size, W // self.patch_size
+        maps = []
+        for i, li in enumerate(self.intermediate_layer_idx):
+            conv = self.projects[i]
+            pos = pos_embed_map(conv.out_channels, gh, gw, W, H, tokens_list[li].device) if self.pos_embed else None
+            x = self._tp(tokens_list[li], s0, s1, psi, gh, gw, self.norm, i, conv, pos)
+            maps.append(self.resize_layers[i](x))
+        return maps
+
+    def _forward_impl(self, tokens_list, images, psi, s0, s1):
+        _, _, _, H, W = images.shape
+        S = s1 - s0
+        gh, gw = H // self.patch_size, W // self.patch_size
+        maps = self._token_maps(tokens_list, psi, s0, s1, H, W)
+        out, side = self.scratch_forward(maps)
+        out = custom_interpolate(out, (int(gh * self.patch_size / self.down_ratio),
+                                       int(gw * self.patch_size / self.down_ratio)))
+        if self.pos_embed:
+            xp, yp = pos_embed_xy(out.shape[1], out.shape[2], out.shape[3], W, H, out.device)
+            half = out.shape[1] // 2
+            out[:, :half] += xp
+            out[:, half:] += yp
+        if self.for_tracker:
+            return out.view(1, S, *out.shape[1:])
+        out = self.scratch.output_conv2(out)
+        preds, conf = activate_head(out, activation=self.activation, conf_activation=self.conf_activation)
+        preds = preds.reshape(1, S, *preds.shape[1:])
+        conf = conf.reshape(1, S, *conf.shape[1:])
+        return (preds, conf, side) if self.use_point_feat else (preds, conf)
+
+    def scratch_forward(self, features: List[torch.Tensor]):
+        l1, l2, l3, l4 = features
+        sc = self.scratch
+        r1, r2, r3, r4 = sc.layer1_rn(l1), sc.layer2_rn(l2), sc.layer3_rn(l3), sc.layer4_rn(l4)
+        out4 = sc.refinenet4(r4, size=r3.shape[2:])
+        out3 = sc.refinenet3(out4, r3, size=r2.shape[2:])
+        out2 = sc.refinenet2(out3, r2, size=r1.shape[2:])
+        out1 = sc.refinenet1(out2, r1)
+        return sc.output_conv1(out1), (out2, out3, out4)

@@ -1,0 +1,237 @@
+"""Window attention stages of the part head (reference iggt/heads/window_sa.py:26-545).
+
+`SwinSA` = LayerNorm -> HAB (8x8 window self-attention, 4 heads x 32, no relative bias because the
+reference passes the index tensor into an unused RoPE slot, appendix D.5; plus a 0.01-weighted
+conv/channel-attention branch and an MLP) -> LayerNorm -> 3 convs.
+`SwinCA` = the same wrapper around OCAB: 8x8 query windows attending to 12x12 overlapping key/value
+windows (unfold stride 8, pad 2) with a learned relative-position bias.
+
+Two reference behaviours are reproduced on purpose because trained weights depend on them:
+  * OCAB query windows are cut from the *NCHW* tensor with an NHWC window routine
+    (window_sa.py:280,286-287): `_ocab_query_windows` below applies the very same index
+    permutation (appendix D.4);
+  * map sizes must be multiples of the window (8): the reference fails in calculate_mask
+    (window_sa.py:401-415); here a ValueError states the constraint.
+Round-1 execution: PyTorch-ROCm fp32 ops on the GPU (next to move to HIP).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .block import MemEffAttention
+
+
+def window_partition(x, ws):
+    b, h, w, c = x.shape
+    x = x.view(b, h // ws, ws, w // ws, ws, c)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(-1, ws, ws, c)
+
+
+def window_reverse(windows, ws, h, w):
+    b = windows.shape[0] // ((h // ws) * (w // ws))
+    x = windows.view(b, h // ws, w // ws, ws, ws, -1)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, -1)
+
+
+def _check_window_grid(h, w, ws):
+    if h % ws or w % ws:
+        raise ValueError(f"part-head window attention needs map sizes that are multiples of {ws}, got "
+                         f"{h}x{w} (image H and W must be multiples of 28; reference window_sa.py:73,411)")
+
+
+class ChannelAttention(nn.Module):
+    def __init__(self, num_feat, squeeze_factor=16):
+        super().__init__()
+        self.attention = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(num_feat, num_feat // squeeze_factor, 1),
+                                       nn.ReLU(inplace=True), nn.Conv2d(num_feat // squeeze_factor, num_feat, 1),
+                                       nn.Sigmoid())
+
+    def forward(self, x):
+        return x * self.attention(x)
+
+
+class CAB(nn.Module):
+    def __init__(self, num_feat, compress_ratio=3, squeeze_factor=30):
+        super().__init__()
+        self.cab = nn.Sequential(nn.Conv2d(num_feat, num_feat // compress_ratio, 3, 1, 1), nn.GELU(),
+                                 nn.Conv2d(num_feat // compress_ratio, num_feat, 3, 1, 1),
+                                 ChannelAttention(num_feat, squeeze_factor))
+
+    def forward(self, x):
+        return self.cab(x)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class _TokenNorm(nn.Module):
+    """`patch_embed` of the reference wrapper: flatten NCHW to tokens + LayerNorm (window_sa.py:123-137)."""
+
+    def __init__(self, embed_dim, norm_layer):
+        super().__init__()
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+    def forward(self, x):
+        x = x.flatten(2).transpose(1, 2)
+        return self.norm(x) if self.norm is not None else x
+
+
+class HAB(nn.Module):
+    def __init__(self, dim, input_resolution, num_heads, window_size=7, shift_size=0, compress_ratio=3,
+                 squeeze_factor=30, conv_scale=0.01, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop=0.0,
+                 attn_drop=0.0, drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        assert shift_size == 0, "IGGT uses un-shifted windows only (window_sa.py:366)"
+        self.dim, self.window_size, self.conv_scale = dim, window_size, conv_scale
+        self.norm1 = norm_layer(dim)
+        self.attn = MemEffAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.conv_block = CAB(num_feat=dim, compress_ratio=compress_ratio, squeeze_factor=squeeze_factor)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), act_layer=act_layer)
+
+    def forward(self, x, x_size, rpi_sa=None, attn_mask=None):
+        h, w = x_size
+        b, _, c = x.shape
+        ws = self.window_size
+        y = self.norm1(x).view(b, h, w, c)
+        conv_x = self.conv_block(y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).reshape(b, h * w, c)
+        win = window_partition(y, ws).view(-1, ws * ws, c)
+        att = window_reverse(self.attn(win).view(-1, ws, ws, c), ws, h, w).view(b, h * w, c)
+        x = x + att + conv_x * self.conv_scale
+        return x + self.mlp(self.norm2(x))
+
+
+def _ocab_query_windows(q_bhwc, ws):
+    """Reference OCAB cuts query windows out of q.permute(0,3,1,2) (NCHW) with the NHWC partition
+    routine and then reinterprets the buffer as [-1, ws*ws, c] (window_sa.py:280,286-287)."""
+    b, h, w, c = q_bhwc.shape
+    q = q_bhwc.permute(0, 3, 1, 2)                      # [b, c, h, w] read as (b, "h"=c, "w"=h, "c"=w)
+    q = q.reshape(b, c // ws, ws, h // ws, ws, w).permute(0, 1, 3, 2, 4, 5)
+    return q.reshape(-1, ws * ws, c)
+
+
+class OCAB(nn.Module):
+    def __init__(self, dim, input_resolution, window_size, overlap_ratio, num_heads, qkv_bias=True,
+                 qk_scale=None, mlp_ratio=2, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim, self.window_size, self.num_heads = dim, window_size, num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.overlap_win_size = int(window_size * overlap_ratio) + window_size
+        self.norm1 = norm_layer(dim)
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.k = nn.Linear(dim, dim, bias=qkv_bias)
+        self.v = nn.Linear(dim, dim, bias=qkv_bias)
+        self.relative_position_bias_table = nn.Parameter(
+            torch.zeros((window_size + self.overlap_win_size - 1) ** 2, num_heads))
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+        self.proj = nn.Linear(dim, dim)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), act_layer=nn.GELU)
+
+    def forward(self, x, k, v, x_size, rpi):
+        h, w = x_size
+        b, _, c = x.shape
+        ws, ow, nh = self.window_size, self.overlap_win_size, self.num_heads
+        d = c // nh
+        shortcut = x
+        q = self.q(self.norm1(x)).view(b, h, w, c)
+        kk = self.k(self.norm1(k)).view(b, h, w, c).permute(0, 3, 1, 2)
+        vv = self.v(self.norm1(v)).view(b, h, w, c).permute(0, 3, 1, 2)
+        qw = _ocab_query_windows(q, ws)                                              # [b*nw, 64, c]
+        pad = (ow - ws) // 2
+        kv = F.unfold(torch.cat((kk, vv), 1), kernel_size=(ow, ow), stride=ws, padding=pad)  # [b, 2c*ow*ow, nw]
+        nw = kv.shape[-1]
+        kv = kv.view(b, 2, c, ow * ow, nw).permute(1, 0, 4, 3, 2).reshape(2, b * nw, ow * ow, c)
+        qh = qw.view(-1, ws * ws, nh, d).transpose(1, 2)
+        kh = kv[0].view(-1, ow * ow, nh, d).transpose(1, 2)
+        vh = kv[1].view(-1, ow * ow, nh, d).transpose(1, 2)
+        bias = self.relative_position_bias_table[rpi.reshape(-1)].view(ws * ws, ow * ow, nh).permute(2, 0, 1)
+        o = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=bias.unsqueeze(0).contiguous(), scale=self.scale)
+        o = o.transpose(1, 2).reshape(-1, ws, ws, c)
+        x = self.proj(window_reverse(o, ws, h, w).view(b, h * w, c)) + shortcut
+        return x + self.mlp(self.norm2(x))
+
+
+class SwinSA(nn.Module):
+    def __init__(self, img_size=320, patch_size=1, out_chans=128, embed_dim=128, num_heads=6, window_size=16,
+                 compress_ratio=3, squeeze_factor=30, conv_scale=0.01, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
+                 drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, norm_layer=nn.LayerNorm, patch_norm=True,
+                 upscale=2, img_range=1.0, upsampler="pixelshuffle", resi_connection="1conv", _build_block=True):
+        super().__init__()
+        self.window_size = window_size
+        self.register_buffer("relative_position_index_SA", self.calculate_rpi_sa())
+        self.patch_embed = _TokenNorm(embed_dim, norm_layer if patch_norm else None)
+        if _build_block:
+            self.atten_block = HAB(dim=embed_dim, input_resolution=(img_size, img_size), num_heads=num_heads,
+                                   window_size=window_size, shift_size=0, compress_ratio=compress_ratio,
+                                   squeeze_factor=squeeze_factor, conv_scale=conv_scale, mlp_ratio=mlp_ratio,
+                                   qkv_bias=qkv_bias, qk_scale=qk_scale, norm_layer=norm_layer)
+        self.norm = norm_layer(embed_dim)
+        self.conv_after_body = nn.Conv2d(embed_dim, embed_dim, 3, 1, 1) if resi_connection == "1conv" else nn.Identity()
+        self.conv_before_upsample = nn.Sequential(nn.Conv2d(embed_dim, 64, 3, 1, 1), nn.LeakyReLU(inplace=True))
+        self.conv_last = nn.Conv2d(64, out_chans, 3, 1, 1)
+
+    def calculate_rpi_sa(self):
+        ws = self.window_size
+        coords = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij")).flatten(1)
+        rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+        rel[:, :, 0] += ws - 1
+        rel[:, :, 1] += ws - 1
+        rel[:, :, 0] *= 2 * ws - 1
+        return rel.sum(-1)
+
+    def _tail(self, body, x):
+        x = self.conv_after_body(body) + x
+        return self.conv_last(self.conv_before_upsample(x)).permute(0, 2, 3, 1).contiguous()
+
+    def forward(self, x):
+        """x NHWC -> NHWC."""
+        x = x.permute(0, 3, 1, 2)
+        b, c, h, w = x.shape
+        _check_window_grid(h, w, self.window_size)
+        t = self.atten_block(self.patch_embed(x), (h, w))
+        body = self.norm(t).transpose(1, 2).reshape(b, c, h, w)
+        return self._tail(body, x)
+
+
+class SwinCA(SwinSA):
+    def __init__(self, img_size=320, patch_size=1, out_chans=128, embed_dim=128, num_heads=6, window_size=16,
+                 overlap_ratio=0.5, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0,
+                 norm_layer=nn.LayerNorm, patch_norm=True, upscale=2, img_range=1.0, upsampler="pixelshuffle",
+                 resi_connection="1conv"):
+        super().__init__(img_size=img_size, patch_size=patch_size, out_chans=out_chans, embed_dim=embed_dim,
+                         num_heads=num_heads, window_size=window_size, norm_layer=norm_layer,
+                         patch_norm=patch_norm, resi_connection=resi_connection, _build_block=False)
+        self.overlap_ratio = overlap_ratio
+        self.atten_block = OCAB(dim=embed_dim, input_resolution=(img_size, img_size), window_size=window_size,
+                                overlap_ratio=overlap_ratio, num_heads=num_heads, qkv_bias=qkv_bias,
+                                qk_scale=qk_scale, mlp_ratio=mlp_ratio, norm_layer=norm_layer)
+        self.register_buffer("relative_position_index_OCA", self.calculate_rpi_oca())
+
+    def calculate_rpi_oca(self):
+        wo = self.window_size
+        we = wo + int(self.overlap_ratio * wo)
+        co = torch.stack(torch.meshgrid([torch.arange(wo), torch.arange(wo)], indexing="ij")).flatten(1)
+        ce = torch.stack(torch.meshgrid([torch.arange(we), torch.arange(we)], indexing="ij")).flatten(1)
+        rel = (ce[:, None, :] - co[:, :, None]).permute(1, 2, 0).contiguous()
+        rel[:, :, 0] += wo - we + 1
+        rel[:, :, 1] += wo - we + 1
+        rel[:, :, 0] *= wo + we - 1
+        return rel.sum(-1)
+
+    def forward(self, x, k, v):
+        x, k, v = (t.permute(0, 3, 1, 2) for t in (x, k, v))
+        b, c, h, w = x.shape
+        _check_window_grid(h, w, self.window_size)
+        t = self.atten_block(self.patch_embed(x), self.patch_embed(k), self.patch_embed(v), (h, w),
+                             self.relative_position_index_OCA)
+        body = self.norm(t).transpose(1, 2).reshape(b, c, h, w)
+        return self._tail(body, x)

@@ -1,0 +1,210 @@
+"""Transformer block modules with the reference's names/parameters, executed by HIP kernels.
+
+Mirrors reference iggt/layers/{attention.py:21-98, mlp.py:16-40, layer_scale.py:15-27,
+block.py:27-107,210-259}.  Parameters stay fp32 `nn.Parameter`s under the reference's state-dict
+keys (checkpoint contract); bf16 MFMA copies of the GEMM weights are packed
+lazily (`packed()`), keyed on the parameter version so `load_state_dict` / `.to()` invalidate them.
+
+Numerics = the reference's GPU mode (demo.py:193-195, autocast bf16): LayerNorm, q/k-norm, RoPE,
+LayerScale and the residual stream in fp32; GEMM and attention operands bf16 with fp32 accumulate.
+
+Execution is in place on a flat fp32 token matrix x[T, C] (`Block.forward_inplace`); the
+`forward(x, pos)` signatures of the reference are kept as thin wrappers.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _C
+
+
+class LayerScale(nn.Module):
+    def __init__(self, dim: int, init_values: float = 1e-5, inplace: bool = False):
+        super().__init__()
+        self.inplace = inplace
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+    def forward(self, x):  # only used outside the fused path
+        return x * self.gamma
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0,
+                 bias=True):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features, bias=bias)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features, bias=bias)
+        self.drop = nn.Dropout(drop)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=True, proj_bias=True, attn_drop=0.0, proj_drop=0.0,
+                 norm_layer=nn.LayerNorm, qk_norm=False, fused_attn=True, rope=None):
+        super().__init__()
+        assert dim % num_heads == 0
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.fused_attn = fused_attn
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.q_norm = norm_layer(self.head_dim) if qk_norm else nn.Identity()
+        self.k_norm = norm_layer(self.head_dim) if qk_norm else nn.Identity()
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim, bias=proj_bias)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.rope = rope
+        self.qk_norm = qk_norm
+
+
+MemEffAttention = Attention  # reference attention.py:80-98 falls back to Attention.forward (xformers off)
+
+
+class Workspace:
+    """Re-usable device buffers for the block engine (sized for the largest T seen)."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, name, shape, dtype, device):
+        n = 1
+        for s in shape:
+            n *= s
+        cur = self._bufs.get(name)
+        if cur is None or cur.numel() < n or cur.dtype != dtype or cur.device != device:
+            cur = torch.empty(n, dtype=dtype, device=device)
+            self._bufs[name] = cur
+        return cur[:n].view(*shape)
+
+
+def _bf16_weight(lin: nn.Linear):
+    return lin.weight.detach().to(torch.bfloat16).contiguous()
+
+
+class Block(nn.Module):
+    """x += ls1(attn(norm1(x))); x += ls2(mlp(norm2(x)))   (reference block.py:105-106)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, proj_bias=True, ffn_bias=True, drop=0.0,
+                 attn_drop=0.0, init_values=None, drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 attn_class=Attention, ffn_layer=Mlp, qk_norm=False, fused_attn=True, rope=None):
+        super().__init__()
+        self.dim = dim
+        self.norm1 = norm_layer(dim)
+        self.attn = attn_class(dim, num_heads=num_heads, qkv_bias=qkv_bias, proj_bias=proj_bias,
+                               attn_drop=attn_drop, proj_drop=drop, qk_norm=qk_norm, fused_attn=fused_attn,
+                               rope=rope)
+        self.ls1 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = ffn_layer(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer,
+                             drop=drop, bias=ffn_bias)
+        self.ls2 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
+        self.sample_drop_ratio = drop_path
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------------------------------
+    def packed(self):
+        """bf16 copies of the four GEMM weights + fp32 epilogue vectors, rebuilt when params change."""
+        ps = (self.attn.qkv.weight, self.attn.proj.weight, self.mlp.fc1.weight, self.mlp.fc2.weight)
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        if self._packed_key != key:
+            dev = ps[0].device
+            f32 = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
+            ones = lambda: torch.ones(self.dim, device=dev)  # noqa: E731
+            self._packed = dict(
+                w_qkv=_bf16_weight(self.attn.qkv), b_qkv=f32(self.attn.qkv.bias),
+                w_proj=_bf16_weight(self.attn.proj), b_proj=f32(self.attn.proj.bias),
+                w_fc1=_bf16_weight(self.mlp.fc1), b_fc1=f32(self.mlp.fc1.bias),
+                w_fc2=_bf16_weight(self.mlp.fc2), b_fc2=f32(self.mlp.fc2.bias),
+                g1=f32(self.ls1.gamma) if isinstance(self.ls1, LayerScale) else ones(),
+                g2=f32(self.ls2.gamma) if isinstance(self.ls2, LayerScale) else ones(),
+                n1w=f32(self.norm1.weight), n1b=f32(self.norm1.bias),
+                n2w=f32(self.norm2.weight), n2b=f32(self.norm2.bias),
+            )
+            if self.attn.qk_norm:
+                self._packed.update(qw=f32(self.attn.q_norm.weight), qb=f32(self.attn.q_norm.bias),
+                                    kw=f32(self.attn.k_norm.weight), kb=f32(self.attn.k_norm.bias))
+            self._packed_key = key
+        return self._packed
+
+    # ------------------------------------------------------------------------------------------
+    def forward_inplace(self, x2d: torch.Tensor, ws: Workspace, *, batch: int, tokens: int,
+                        rope_geom: Optional[dict] = None, kv_gather=None, q_rows_per_wg: int = 0):
+        """Run the block in place on x2d [T, C] fp32 (T = batch * tokens rows; attention is computed
+        independently per `batch` group of `tokens` rows).
+
+        rope_geom: dict(P=tokens per view, gw=grid width, patch_start=5, cos=..., sin=...) when the block
+        has q/k-norm + RoPE (aggregator blocks); None for the DINOv2 blocks.
+        kv_gather: optional callable(kv_local [T, 2C] bf16) -> kv_all [T_all, 2C] (multi-GPU global
+        attention: RCCL all-gather of the post-RoPE K and the V rows).
+        """
+        if x2d.dtype != torch.float32 or x2d.dim() != 2 or x2d.stride(1) != 1:
+            raise _C.HipExtensionError("Block.forward_inplace expects a row-major fp32 [T, C] matrix")
+        if self.attn.head_dim != 64:
+            raise _C.HipExtensionError("HIP flash attention is built for head_dim 64")
+        T, C = x2d.shape
+        assert T == batch * tokens and C == self.dim
+        dev = x2d.device
+        pk = self.packed()
+        H = self.attn.num_heads
+        xn = ws.get("xn", (T, C), torch.bfloat16, dev)
+        qkv = ws.get("qkv", (T, 3 * C), torch.bfloat16, dev)
+        ao = ws.get("ao", (T, C), torch.bfloat16, dev)
+        hid = ws.get("hid", (T, pk["w_fc1"].shape[0]), torch.bfloat16, dev)
+
+        _C.layernorm(x2d, pk["n1w"], pk["n1b"], xn, self.norm1.eps)
+        _C.gemm_bf16(xn, pk["w_qkv"], qkv, bias=pk["b_qkv"])
+        k_src, v_src, kv_rs, Nk, k_bs = qkv[:, C:], qkv[:, 2 * C:], 3 * C, tokens, tokens * 3 * C
+        if self.attn.qk_norm:
+            assert rope_geom is not None
+            if kv_gather is None:
+                _C.qknorm_rope(qkv, qkv, qkv[:, C:], None, pk["qw"], pk["qb"], pk["kw"], pk["kb"],
+                               rope_geom["cos"], rope_geom["sin"], T, rope_geom["P"], rope_geom["gw"],
+                               rope_geom["patch_start"], self.attn.q_norm.eps)
+            else:
+                kv_local = ws.get("kv_local", (T, 2 * C), torch.bfloat16, dev)
+                _C.qknorm_rope(qkv, qkv, kv_local, kv_local[:, C:], pk["qw"], pk["qb"], pk["kw"], pk["kb"],
+                               rope_geom["cos"], rope_geom["sin"], T, rope_geom["P"], rope_geom["gw"],
+                               rope_geom["patch_start"], self.attn.q_norm.eps)
+                kv_all = kv_gather(kv_local)
+                assert batch == 1
+                k_src, v_src, kv_rs, Nk, k_bs = kv_all, kv_all[:, C:], 2 * C, kv_all.shape[0], 0
+        elif kv_gather is not None:
+            raise _C.HipExtensionError("kv_gather needs a q/k-norm block")
+        _C.flash_attn_d64(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
+                          tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,
+                          self.attn.scale, q_rows_per_wg)
+        _C.gemm_bf16(ao, pk["w_proj"], x2d, bias=pk["b_proj"], gamma=pk["g1"], accumulate=True)
+        _C.layernorm(x2d, pk["n2w"], pk["n2b"], xn, self.norm2.eps)
+        _C.gemm_bf16(xn, pk["w_fc1"], hid, bias=pk["b_fc1"], act=1)
+        _C.gemm_bf16(hid, pk["w_fc2"], x2d, bias=pk["b_fc2"], gamma=pk["g2"], accumulate=True)
+        return x2d
+
+    def forward(self, x: torch.Tensor, pos=None) -> torch.Tensor:
+        """Reference signature (block.py:81): x [B, N, C] -> new tensor.  `pos` must be the standard
+        aggregator layout (5 special tokens then a row-major grid) when the block has RoPE; it is only
+        inspected on the host for its shape (no device sync)."""
+        B, N, C = x.shape
+        out = x.detach().float().contiguous().clone().view(B * N, C)
+        rope_geom = None
+        if self.attn.qk_norm and self.attn.rope is not None:
+            raise _C.HipExtensionError(
+                "RoPE blocks need the token-grid geometry: call Block.forward_inplace(..., rope_geom=...) "
+                "or run them through Aggregator")
+        self.forward_inplace(out, _default_ws(x.device), batch=B, tokens=N, rope_geom=rope_geom)
+        return out.view(B, N, C)
+
+
+NestedTensorBlock = Block  # reference block.py:210-259: Tensor input -> Block.forward
+
+_WS = {}
+
+
+def _default_ws(device) -> Workspace:
+    key = str(device)
+    if key not in _WS:
+        _WS[key] = Workspace()
+    return _WS[key]

@@ -1,0 +1,125 @@
+"""IGGT / VGGT model API -- drop-in for `from iggt.models.vggt import IGGT, VGGT` (reference
+iggt/models/vggt.py:14-230; caller: demo.py:35,102-121,195).
+
+Same constructor, sub-module attribute names, state-dict keys (track_head excepted, see below) and
+output dict (keys, shapes, fp32) as the reference; the forward runs on MI355X HIP kernels (aggregator,
+head token stages) and PyTorch-ROCm ops (conv pyramids, round 1).  There is no CPU path: inputs and
+parameters must live on the GPU and libiggt_hip.so must be built, otherwise forward raises.
+
+Deliberate differences, all documented in DESIGN.md:
+  * S > 12 views works (the reference's chunked head path is broken there, appendix D.1): heads
+    behave as the reference does unchunked, which is bit-identical to chunking where both exist;
+  * `part_feat` needs H, W in 28N exactly like the reference (appendix D.2); for other sizes the
+    reference raises inside the part head after having computed everything else -- here
+    `IGGT(..., part_on_invalid_grid="skip")` (default "raise") returns the geometry outputs only;
+  * `track_head` (only run when `query_points` is given, vggt.py:220; demo never does) is not built:
+    its 134 checkpoint tensors are ignored by `load_state_dict(strict=False)` (what demo.py:116 uses)
+    and `query_points` raises NotImplementedError;
+  * multi-GPU: `set_view_shard(ViewShard())` makes `forward` take this rank's slice of the views.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+try:  # keeps from_pretrained / save_pretrained of the reference class (vggt.py:4,132)
+    from huggingface_hub import PyTorchModelHubMixin
+except Exception:  # pragma: no cover
+    class PyTorchModelHubMixin:  # type: ignore
+        pass
+
+from .. import _C
+from ..dist import ViewShard
+from ..heads.adaptor import SamProjector
+from ..heads.camera_head import CameraHead
+from ..heads.dpt_head import DPTHead
+from ..heads.part_head import PartHead
+from .aggregator import Aggregator
+
+
+class _Base(nn.Module, PyTorchModelHubMixin):
+    def set_view_shard(self, shard: Optional[ViewShard]):
+        self.aggregator.shard = shard
+        return self
+
+    def _common(self, images, query_points):
+        if query_points is not None:
+            raise NotImplementedError("TrackHead / query_points is out of scope of the MI355X hot path "
+                                      "(reference vggt.py:220-227; demo.py never passes query_points)")
+        if images.dim() == 4:
+            images = images.unsqueeze(0)
+        if not images.is_cuda:
+            raise _C.HipExtensionError("IGGT forward runs on the MI355X only: move model and images to 'cuda' "
+                                       "(no CPU fallback; the CPU restatement lives in oracle/ for tests)")
+        _C.load()
+        return images.float().contiguous()
+
+    def _camera(self, tokens_list):
+        shard = self.aggregator.shard
+        cam = None
+        if shard is not None and shard.world > 1:
+            local = tokens_list[-1][0, :, 0]                      # [S_local, 2C]
+            cam = shard.all_gather_rows(local)[None]               # [1, S, 2C]
+        return self.camera_head(tokens_list, camera_tokens=cam)
+
+
+class VGGT(_Base):
+    def __init__(self, img_size=518, patch_size=14, embed_dim=1024, only_train_adaptor=False):
+        super().__init__()
+        self.aggregator = Aggregator(img_size=img_size, patch_size=patch_size, embed_dim=embed_dim)
+        self.camera_head = CameraHead(dim_in=2 * embed_dim)
+        self.point_head = DPTHead(dim_in=2 * embed_dim, output_dim=4, activation="inv_log", conf_activation="expp1",
+                                  use_point_feat=False)
+        self.depth_head = DPTHead(dim_in=2 * embed_dim, output_dim=2, activation="exp", conf_activation="expp1",
+                                  use_point_feat=False)
+        self.track_head = None
+
+    @torch.no_grad()
+    def forward(self, images, query_points=None):
+        images = self._common(images, query_points)
+        tokens, psi = self.aggregator(images)
+        pred = {"pose_enc": self._camera(tokens)}
+        pred["depth"], pred["depth_conf"] = self.depth_head(tokens, images=images, patch_start_idx=psi)
+        pred["world_points"], pred["world_points_conf"] = self.point_head(tokens, images=images, patch_start_idx=psi)
+        pred["images"] = images
+        return pred
+
+
+class IGGT(_Base):
+    def __init__(self, img_size=518, patch_size=14, embed_dim=1024, only_train_adaptor=False,
+                 part_on_invalid_grid: str = "raise"):
+        super().__init__()
+        self.aggregator = Aggregator(img_size=img_size, patch_size=patch_size, embed_dim=embed_dim)
+        self.camera_head = CameraHead(dim_in=2 * embed_dim)
+        self.point_head = DPTHead(dim_in=2 * embed_dim, output_dim=4, activation="inv_log", conf_activation="expp1",
+                                  use_point_feat=True)
+        self.depth_head = DPTHead(dim_in=2 * embed_dim, output_dim=2, activation="exp", conf_activation="expp1",
+                                  use_point_feat=False)
+        self.track_head = None
+        self.part_adaptor = SamProjector(dim_in=2 * embed_dim, out_channels=[256, 256, 256, 256], pos_embed=False)
+        self.part_head = PartHead(dim_in=2 * embed_dim, output_dim=8, activation="norm")
+        assert part_on_invalid_grid in ("raise", "skip")
+        self.part_on_invalid_grid = part_on_invalid_grid
+
+    @torch.no_grad()
+    def forward(self, images, query_points=None):
+        """images [S,3,H,W] or [1,S,3,H,W] in [0,1] (this rank's views when sharded) -> dict with
+        pose_enc (list of 4 x [1,S_all,9]), depth [1,S,H,W,1], depth_conf [1,S,H,W],
+        world_points [1,S,H,W,3], world_points_conf [1,S,H,W], part_feat [1,S,8,H,W], images."""
+        images = self._common(images, query_points)
+        H, W = images.shape[-2:]
+        part_ok = (H % 28 == 0) and (W % 28 == 0)
+        if not part_ok and self.part_on_invalid_grid == "raise":
+            raise ValueError(f"IGGT part head needs H, W multiples of 28, got {H}x{W} (the reference fails in "
+                             "window_sa.py:73); construct IGGT(part_on_invalid_grid='skip') for geometry only")
+        tokens, psi = self.aggregator(images)
+        pred = {"pose_enc": self._camera(tokens)}
+        pred["depth"], pred["depth_conf"] = self.depth_head(tokens, images=images, patch_start_idx=psi)
+        pts, conf, point_feat = self.point_head(tokens, images=images, patch_start_idx=psi)
+        pred["world_points"], pred["world_points_conf"] = pts, conf
+        if part_ok:
+            pyramid, _ = self.part_adaptor(tokens, images=images, patch_start_idx=psi)
+            pred["part_feat"] = self.part_head(list(pyramid.values()), point_feature=point_feat, images=images,
+                                               patch_start_idx=psi)
+        pred["images"] = images
+        return pred

@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the REFERENCE modules (build container only).
+
+TEST INFRASTRUCTURE.  Usage:  python oracle/make_golden.py [case ...]
+
+Imports /root/reference through oracle/ref_shim.py, fills the reference IGGT with the
+seeded synthetic weights of oracle/weights.py, runs the forward path exactly as
+IGGT.forward orchestrates it (reference iggt/models/vggt.py:185-218; sub-modules are
+called directly so that odd patch grids / S>12 can be covered)
+and writes tests/golden/<case>.pt plus tests/golden/state_dict_schema.json.
+
+Large cases store strided samples of the dense maps (key suffix "@s<stride>") so the
+fixtures stay small; tests index the HIP output with the same stride.
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_shim, weights  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+# name: (S, H, W, weight mode, weight seed, image seed, spatial sample stride, token sample stride)
+CASES = {
+    "tiny_s2_56_stress": (2, 56, 56, "stress", 0, 1, 1, 1),
+    "tiny_s3_84x56_stress": (3, 84, 56, "stress", 0, 2, 1, 1),
+    "tiny_s2_56_default": (2, 56, 56, "default", 0, 1, 1, 1),
+    "tiny_s2_70_stress": (2, 70, 70, "stress", 0, 3, 1, 1),  # odd grid: geometry outputs only
+    "tiny_s5_112_stress": (5, 112, 112, "stress", 0, 4, 2, 1),
+    "full_s2_518_stress": (2, 518, 518, "stress", 0, 5, 7, 16),
+    "demo_s3_336x504_stress": (3, 336, 504, "stress", 0, 6, 7, 16),
+}
+
+
+def schema_of(model):
+    sd = model.state_dict()
+    return {k: {"shape": list(v.shape), "dtype": str(v.dtype)} for k, v in sd.items()}
+
+
+def run_case(model, name):
+    S, H, W, mode, wseed, iseed, sstride, tstride = CASES[name]
+    schema = schema_of(model)
+    t0 = time.time()
+    sd = weights.fill_state_dict(schema, seed=wseed, mode=mode)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(m.startswith("track_head.") or not schema[m]["dtype"].startswith("torch.float")
+               for m in missing), missing
+    print(f"[{name}] weights filled in {time.time() - t0:.1f}s", flush=True)
+
+    images = weights.make_images(S, H, W, seed=iseed)[None]  # [1,S,3,H,W]
+    out = {"meta": dict(S=S, H=H, W=W, mode=mode, weight_seed=wseed, image_seed=iseed,
+                        spatial_stride=sstride, token_stride=tstride,
+                        torch=torch.__version__)}
+    cap = {}
+    h = model.aggregator.patch_embed.register_forward_hook(
+        lambda m, i, o: cap.__setitem__("dino", o["x_norm_patchtokens"].detach().clone()))
+    t0 = time.time()
+    with torch.no_grad():
+        tokens, psi = model.aggregator(images)
+        h.remove()
+        pose = model.camera_head(tokens)
+        depth, depth_conf = model.depth_head(tokens, images=images, patch_start_idx=psi, frames_chunk_size=None)
+        pts, pts_conf, point_feat = model.point_head(tokens, images=images, patch_start_idx=psi,
+                                                     frames_chunk_size=None)
+        part_ok = (H % 28 == 0) and (W % 28 == 0)
+        if part_ok:
+            ada, _pos = model.part_adaptor(tokens, images=images, patch_start_idx=psi)
+            part = model.part_head(list(ada.values()), point_feature=point_feat, images=images,
+                                   patch_start_idx=psi, frames_chunk_size=None)
+    print(f"[{name}] reference forward {time.time() - t0:.1f}s", flush=True)
+
+    def sp(t, dims):  # strided spatial sample over dims (h, w)
+        if sstride == 1:
+            return t.clone()
+        idx = [slice(None)] * t.ndim
+        for d in dims:
+            idx[d] = slice(0, None, sstride)
+        return t[tuple(idx)].clone()
+
+    ts = tstride
+    out["dino"] = cap["dino"][:, ::ts].clone()                       # [S, g2/ts, 1024]
+    for li in (4, 11, 17, 23):
+        out[f"tokens_{li}"] = tokens[li][:, :, ::ts].clone()          # [1,S,P/ts,2048]
+    out["tokens_23_special"] = tokens[23][:, :, :5].clone()
+    out["pose_enc"] = torch.stack(pose, 0)                            # [4,1,S,9]
+    out["depth"] = sp(depth, (2, 3))
+    out["depth_conf"] = sp(depth_conf, (2, 3))
+    out["world_points"] = sp(pts, (2, 3))
+    out["world_points_conf"] = sp(pts_conf, (2, 3))
+    if sstride == 1:
+        for i, f in enumerate(point_feat):
+            out[f"point_feat_{i}"] = f.clone()
+    if part_ok:
+        out["part_feat"] = sp(part, (3, 4))
+        if sstride == 1:
+            for k, v in ada.items():
+                out[f"adaptor_{k}"] = v.clone()
+    # whole-tensor statistics pin the un-sampled part too
+    stats = {}
+    for k, v in [("depth", depth), ("depth_conf", depth_conf), ("world_points", pts),
+                 ("world_points_conf", pts_conf)] + ([("part_feat", part)] if part_ok else []):
+        stats[k] = dict(mean=float(v.double().mean()), abs_sum=float(v.double().abs().sum()),
+                        std=float(v.double().std()))
+    out["stats"] = stats
+    path = os.path.join(GOLDEN_DIR, name + ".pt")
+    torch.save(out, path)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)", flush=True)
+
+
+def main():
+    assert ref_shim.available(), "reference tree not found"
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    torch.manual_seed(0)
+    t0 = time.time()
+    model = ref_shim.build_reference_iggt(fast_init=True)
+    print(f"reference IGGT built in {time.time() - t0:.1f}s", flush=True)
+    schema = schema_of(model)
+    with open(os.path.join(GOLDEN_DIR, "state_dict_schema.json"), "w") as f:
+        json.dump(schema, f, indent=0, sort_keys=True)
+    # integer buffers (relative position indices) are structural, save their values
+    ints = {k: v.clone() for k, v in model.state_dict().items() if not v.dtype.is_floating_point and v.numel() > 1}
+    torch.save(ints, os.path.join(GOLDEN_DIR, "int_buffers.pt"))
+    names = sys.argv[1:] or list(CASES)
+    for n in names:
+        run_case(model, n)
+
+
+if __name__ == "__main__":
+    main()
