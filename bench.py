@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- views/sec of the IGGT forward (N-view 518x518) on N MI355X GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W                      (single GPU)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N ranks, RCCL)
+
+Workload (BASELINE.json configs[2] / [3]): 32 synthetic views @ 518x518, end-to-end forward =
+DINOv2 backbone + 24 x (frame, global) blocks + camera head + depth head + point head, random-init
+weights of the reference architecture (no checkpoint reachable), bf16 MFMA operands with fp32
+accumulation = the reference's own GPU precision (demo.py:193-195).  518 is not a multiple of 28, where
+the reference's part head raises, so the step produces the geometry outputs --
+exactly what the reference can produce at this size.  One "step" = one full forward of all views.
+Views are sharded over ranks ("strong" scaling: 32 views total for every N); the only data-path
+collective is the K/V all-gather in front of each global attention (iggt_official_amd/dist.py).
+
+Prints ONE JSON line (rank 0) with value = total views / second, plus
+  "roofline": global-attention flash kernel, algorithmic FLOPs (4*Nq*Nk*C per launch) / mean launch
+              duration measured with HIP events on the launch stream inside the timed region, against
+              the 2.5 PFLOP/s dense bf16 MFMA peak;
+  "cpu_baseline": the CPU restatement of the reference (oracle/restate.py, kind "port") timed on this
+              box's host cores on a bounded sample (2 views @ 518x518), rank 0 / N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def cpu_baseline(sample_views, size):
+    """Oracle port on the host cores: views/s of a `sample_views`-view forward (geometry outputs)."""
+    import json as _json
+
+    from oracle import restate, weights
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_schema.json")) as f:
+        schema = _json.load(f)
+    sd = weights.fill_state_dict(schema, seed=0, mode="default")
+    images = weights.make_images(sample_views, size, size, seed=0)
+    t0 = time.perf_counter()
+    restate.iggt_forward(sd, images, with_part=False)
+    dt = time.perf_counter() - t0
+    return {"value": sample_views / dt, "unit": "views/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_views} views @ {size}x{size}, full geometry forward (aggregator + camera/depth/"
+                      f"point heads), fp32 torch CPU, {cores} threads, single run {dt:.1f}s; global attention "
+                      "is O(S^2): the 32-view CPU rate per view would be lower"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--views", type=int, default=32)
+    ap.add_argument("--size", type=int, default=518)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-views", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    shard = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from iggt.models.vggt import IGGT
+    from iggt_official_amd import _C, profiling
+    from iggt_official_amd.dist import ViewShard, view_partition
+
+    _C.load()
+    S, H = args.views, args.size
+    if S % world:
+        raise SystemExit(f"--views {S} must be divisible by the number of GPUs {world}")
+    torch.manual_seed(0)  # identical random-init weights on every rank
+    with torch.device(dev):
+        model = IGGT(part_on_invalid_grid="skip").eval()
+    if world > 1:
+        shard = ViewShard()
+        model.set_view_shard(shard)
+    v0, v1 = view_partition(S, world, rank)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    images = torch.rand(S, 3, H, H, generator=g)[v0:v1].to(dev)
+
+    def step():
+        return model(images)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    profiling.enable("global_attn")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    recs = profiling.summarize(profiling.disable("global_attn"))
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert all(torch.isfinite(v).all() for v in out.values() if torch.is_tensor(v))
+
+    if rank == 0:
+        P = 5 + (H // 14) ** 2
+        C = 1024
+        Nq, Nk = (S // world) * P, S * P
+        ms = sum(r[0] for r in recs) / max(len(recs), 1)
+        flops = 4.0 * Nq * Nk * C
+        achieved = flops / (ms * 1e-3) / 1e12
+        line = {
+            "metric": "views/sec (N-view 518^2 forward)",
+            "value": S * args.steps / dt,
+            "unit": "views/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"{S} views @ {H}x{H}, IGGT forward (DINOv2 + 24x(frame,global) + camera/depth/"
+                                   "point heads), random-init weights, views sharded " + f"{S // world}/GPU",
+                       "views": S, "image_size": H, "tokens_per_view": P, "parallelism": f"view-shard x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "flash_attn_d64_kernel (global attention)",
+                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "launches_timed": len(recs), "ms_per_launch": ms,
+                         "flops_per_launch": flops},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.cpu_sample_views, H)
+            except Exception as ex:  # noqa: BLE001
+                line["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

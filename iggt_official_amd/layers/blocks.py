@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from .. import _C
+from .. import _C, profiling
 
 
 class LayerScale(nn.Module):
@@ -174,9 +174,10 @@ class Block(nn.Module):
                 k_src, v_src, kv_rs, Nk, k_bs = kv_all, kv_all[:, C:], 2 * C, kv_all.shape[0], 0
         elif kv_gather is not None:
             raise _C.HipExtensionError("kv_gather needs a q/k-norm block")
-        _C.flash_attn_d64(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
-                          tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,
-                          self.attn.scale, q_rows_per_wg)
+        with profiling.region("global_attn" if batch == 1 else "frame_attn", (batch, tokens, Nk)):
+            _C.flash_attn_d64(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
+                              tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,
+                              self.attn.scale, q_rows_per_wg)
         _C.gemm_bf16(ao, pk["w_proj"], x2d, bias=pk["b_proj"], gamma=pk["g1"], accumulate=True)
         _C.layernorm(x2d, pk["n2w"], pk["n2b"], xn, self.norm2.eps)
         _C.gemm_bf16(xn, pk["w_fc1"], hid, bias=pk["b_fc1"], act=1)

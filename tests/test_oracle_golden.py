@@ -1,0 +1,57 @@
+"""Pin the CPU restatement (oracle/restate.py) against the golden fixtures produced by the REFERENCE
+modules (oracle/make_golden.py): same seeded weights/inputs, fp32 CPU both sides.  Tolerance 2e-5
+relative to the tensor's max (pure fp32 re-association differences)."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+CASES = ["tiny_s2_56_stress", "tiny_s3_84x56_stress", "tiny_s2_70_stress"]
+TOL = 5e-5
+
+
+@pytest.fixture(scope="module")
+def sd(schema):
+    from oracle import weights
+
+    return weights.fill_state_dict(schema, seed=0, mode="stress")
+
+
+def _chk(name, got, ref, tol=TOL):
+    d = float((got.double() - ref.double()).abs().max() / ref.double().abs().max())
+    assert d < tol, (name, d)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_restatement_matches_reference_outputs(sd, case):
+    from oracle import restate, weights
+
+    g = load_golden(case)
+    m = g["meta"]
+    assert m["mode"] == "stress" and m["weight_seed"] == 0
+    images = weights.make_images(m["S"], m["H"], m["W"], seed=m["image_seed"])
+    out = restate.iggt_forward(sd, images)
+    for li in (4, 11, 17, 23):
+        _chk(f"tokens_{li}", out["tokens"][li], g[f"tokens_{li}"])
+    _chk("pose_enc", torch.stack(out["pose_enc"], 0), g["pose_enc"])
+    for k in ("depth", "depth_conf", "world_points", "world_points_conf"):
+        _chk(k, out[k], g[k])
+    for i in range(3):
+        _chk(f"point_feat_{i}", out["point_feat"][i], g[f"point_feat_{i}"])
+    if "part_feat" in g:
+        for i, k in enumerate(("res1", "res2", "res3", "res4")):
+            _chk(f"adaptor_{k}", out["adaptor"][i], g[f"adaptor_{k}"])
+        _chk("part_feat", out["part_feat"], g["part_feat"])
+    else:
+        assert "part_feat" not in out
+
+
+def test_golden_weights_are_reproducible(schema):
+    """The synthetic weights are a pure function of (name, seed, mode): spot-check known values."""
+    from oracle import weights
+
+    w = weights.make_tensor("aggregator.frame_blocks.3.ls1.gamma", (1024,), 0, "stress")
+    assert torch.allclose(w[:4], torch.tensor([0.5007, 0.9852, 0.8057, 0.6321]), atol=1e-4)
+    a = weights.make_tensor("depth_head.scratch.output_conv1.weight", (128, 256, 3, 3), 0, "stress")
+    b = weights.make_tensor("depth_head.scratch.output_conv1.weight", (128, 256, 3, 3), 0, "stress")
+    assert torch.equal(a, b) and abs(float(a.std()) * (256 * 9) ** 0.5 - 1.0) < 0.01
