@@ -252,6 +252,231 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(const AttnParams
     }
 }
 
+// =================================================================================================
+// Ping-pong variant for long sequences (global attention): 8 waves / workgroup, 512 query rows.
+//
+// Two wave groups (A = waves 0-3, B = waves 4-7; wave w and w+4 share a SIMD) run the same
+// per-tile pipeline  QK^T(t) -> softmax(t) -> PV(t)  half a tile apart, in barrier-delimited segments:
+//
+//     segment 2u   : A: MFMA  [PV(u-1), QK^T(u)]      B: VALU  [softmax(u-1)]
+//     segment 2u+1 : A: VALU  [softmax(u)]            B: MFMA  [PV(u-1), QK^T(u)]
+//
+// so on every SIMD one wave feeds the matrix pipe while its partner does the exp/max/sum VALU work
+// (CDNA4 issues MFMA and VALU from different waves concurrently; two waves in the same phase just
+// queue behind each other -- MI355X_MICROARCH "Two waves per SIMD").  LDS "stage" X = {K tile X,
+// V tile X-1} is what both groups read during segments 2X and 2X+1; stages are double-buffered and
+// written one stage ahead by the group that is in its VALU segment (registers are loaded with the
+// next stage at the start of each MFMA segment).  K/V tiles are shared by all 8 waves, halving the
+// L2->LDS traffic per query row relative to the 4-wave kernel.
+template <int QB>
+__global__ __launch_bounds__(512, 2) void flash_attn_d64_pp_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;  // 0 = A, 1 = B
+    const int frow = lane & 31, fhalf = lane >> 5;
+
+    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = work % p.qtiles;
+    const int bh = work / p.qtiles;
+    const int h = bh % p.H, b = bh / p.H;
+    const bf16_t* qb_ptr = p.q + (long)b * p.q_bs + h * 64;
+    const bf16_t* kb_ptr = p.k + (long)b * p.k_bs + h * 64;
+    const bf16_t* vb_ptr = p.v + (long)b * p.v_bs + h * 64;
+    bf16_t* ob_ptr = p.o + (long)b * p.o_bs + h * 64;
+
+    const int q_base = qt * (256 * QB) + wave * (32 * QB);
+    bf16x8 qf[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        int qr = q_base + qb * 32 + frow;
+        qr = qr < p.Nq ? qr : p.Nq - 1;
+        const bf16_t* src = qb_ptr + (long)qr * p.q_rs + 8 * fhalf;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) qf[qb][kc] = *reinterpret_cast<const bf16x8*>(src + 16 * kc);
+    }
+
+    const int NT = (p.Nk + KV_TILE - 1) / KV_TILE;
+    // staging: 512 threads x 16 B = one 64x64 bf16 tile; thread -> (row = tid/8, piece = tid%8)
+    const int ld_row = tid >> 3, ld_piece = tid & 7;
+    u32x4 sk, sv;
+    auto gload = [&](int X) {  // stage X = {K tile X, V tile X-1}
+        sk = u32x4{0, 0, 0, 0};
+        sv = u32x4{0, 0, 0, 0};
+        const int kr = X * KV_TILE + ld_row;
+        if (X < NT && kr < p.Nk) sk = *reinterpret_cast<const u32x4*>(kb_ptr + (long)kr * p.k_rs + ld_piece * 8);
+        const int vr = (X - 1) * KV_TILE + ld_row;
+        if (X >= 1 && vr < p.Nk) sv = *reinterpret_cast<const u32x4*>(vb_ptr + (long)vr * p.v_rs + ld_piece * 8);
+    };
+    auto swrite = [&](int X) {
+        char* sK = smem + (X & 1) * BUF_BYTES;
+        char* sV = sK + K_BYTES;
+        *reinterpret_cast<u32x4*>(sK + swz_off(ld_row, ld_piece)) = sk;
+        *reinterpret_cast<u32x4*>(sV + v_lds_off(ld_row, ld_piece >> 1) + ((ld_piece & 1) << 4)) = sv;
+    };
+
+    f32x16 o[QB][2];
+    f32x16 s[QB][2];
+    bf16x8 pf[QB][2][2];
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = -1e30f;
+        l_run[qb] = 0.f;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][dh][r] = 0.f;
+#pragma unroll
+        for (int kvh = 0; kvh < 2; ++kvh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[qb][kvh][r] = 0.f;
+            pf[qb][kvh][0] = pf[qb][kvh][1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    const int tr_i = lane & 15, tr_g = (lane >> 4) & 1;
+    const float c = p.scale_log2;
+
+    // prologue: stage 0 resident; group B pre-loads stage 1 (it writes it in segment 0)
+    gload(0);
+    swrite(0);
+    if (grp == 1) gload(1);
+    __syncthreads();
+
+    // ---- MFMA segment: PV(t-1) then QK^T(t) ----------------------------------------------------
+    auto mfma_segment = [&](int t) {
+        {
+            const int X = grp ? t + 2 : t + 1;  // next stage this thread has to deliver
+            if (X <= NT) gload(X);
+        }
+        const char* sK = smem + (t & 1) * BUF_BYTES;
+        const char* sV = sK + K_BYTES;
+        if (t >= 1) {
+#pragma unroll
+            for (int kvh = 0; kvh < 2; ++kvh)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int dh = 0; dh < 2; ++dh) {
+                        const int kvb = kvh * 32 + 16 * cc + 4 * fhalf;
+                        const int row0 = kvb + (tr_i >> 2);
+                        const int chunk = dh * 2 + tr_g;
+                        typedef __attribute__((address_space(3))) short4v lds_s4;
+                        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (lds_s4*)(sV + v_lds_off(row0, chunk) + 8 * (tr_i & 3)));
+                        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (lds_s4*)(sV + v_lds_off(row0 + 8, chunk) + 8 * (tr_i & 3)));
+                        typedef short short8v __attribute__((ext_vector_type(8)));
+                        const short8v v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const bf16x8 vf = __builtin_bit_cast(bf16x8, v8);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) o[qb][dh] = mfma32(vf, pf[qb][kvh][cc], o[qb][dh]);
+                    }
+        }
+        if (t < NT) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int kvh = 0; kvh < 2; ++kvh)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[qb][kvh][r] = 0.f;
+#pragma unroll
+            for (int kvh = 0; kvh < 2; ++kvh)
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const bf16x8 kf =
+                        *reinterpret_cast<const bf16x8*>(sK + swz_off(kvh * 32 + frow, 2 * kc + fhalf));
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) s[qb][kvh] = mfma32(kf, qf[qb][kc], s[qb][kvh]);
+                }
+        }
+    };
+    // ---- VALU segment: write stage X, then softmax(t) ---------------------------------------------
+    auto valu_segment = [&](int X, int t) {
+        if (X <= NT) swrite(X);
+        if (t >= 0 && t < NT) {
+            if ((t + 1) * KV_TILE > p.Nk) {
+                const int kv0 = t * KV_TILE + 4 * fhalf;
+#pragma unroll
+                for (int kvh = 0; kvh < 2; ++kvh)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = kv0 + kvh * 32 + (r & 3) + 8 * (r >> 2);
+                        if (kv >= p.Nk) {
+#pragma unroll
+                            for (int qb = 0; qb < QB; ++qb) s[qb][kvh][r] = -INFINITY;
+                        }
+                    }
+            }
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float mx = s[qb][0][0];
+#pragma unroll
+                for (int kvh = 0; kvh < 2; ++kvh)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kvh][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[qb], mx * c);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+                m_run[qb] = m_new;
+                float lsum = 0.f;
+#pragma unroll
+                for (int kvh = 0; kvh < 2; ++kvh) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kvh][r], c, -m_new));
+                        s[qb][kvh][r] = pv;
+                        lsum += pv;
+                    }
+                    pf[qb][kvh][0] = pack8(s[qb][kvh], 0);
+                    pf[qb][kvh][1] = pack8(s[qb][kvh], 8);
+                }
+                l_run[qb] = l_run[qb] * alpha + lsum;
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qb][dh][r] *= alpha;
+            }
+        }
+    };
+
+    // Both groups execute exactly 2*(NT+1) barriers; s_barrier counts arrivals, not program counters.
+    if (grp == 0) {
+        for (int u = 0; u <= NT; ++u) {
+            mfma_segment(u);          // segment 2u
+            __syncthreads();
+            valu_segment(u + 1, u);   // segment 2u+1
+            __syncthreads();
+        }
+    } else {
+        for (int u = 0; u <= NT; ++u) {
+            valu_segment(u + 1, u - 1);  // segment 2u
+            __syncthreads();
+            mfma_segment(u);             // segment 2u+1
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qr = q_base + qb * 32 + frow;
+        const float l = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.0f / l;
+        if (qr < p.Nq) {
+            bf16_t* dst = ob_ptr + (long)qr * p.o_rs + 4 * fhalf;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 w;
+                    w[0] = pack_bf16x2(o[qb][dh][4 * g + 0] * inv, o[qb][dh][4 * g + 1] * inv);
+                    w[1] = pack_bf16x2(o[qb][dh][4 * g + 2] * inv, o[qb][dh][4 * g + 3] * inv);
+                    *reinterpret_cast<u32x2*>(dst + dh * 32 + 8 * g) = w;
+                }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int iggt_flash_attn_bf16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
@@ -278,6 +503,9 @@ extern "C" int iggt_flash_attn_bf16_d64(const void* q, const void* k, const void
     } else if (q_rows_per_wg == 128) {
         p.qtiles = (Nq + 127) / 128;
         hipLaunchKernelGGL(flash_attn_d64_kernel<1>, dim3(B * H * p.qtiles), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (q_rows_per_wg == 512) {
+        p.qtiles = (Nq + 511) / 512;
+        hipLaunchKernelGGL(flash_attn_d64_pp_kernel<2>, dim3(B * H * p.qtiles), dim3(512), 0, (hipStream_t)stream, p);
     } else {
         return -3;
     }

@@ -116,7 +116,9 @@ def _attn_ref(q, k, v, scale):
 
 @pytest.mark.parametrize("B,H,Nq,Nk,tile", [(1, 1, 64, 64, 128), (2, 16, 1374, 1374, 0), (1, 16, 4122, 4122, 0),
                                             (1, 2, 300, 777, 128), (1, 2, 300, 777, 256), (3, 4, 21, 21, 0),
-                                            (1, 16, 2748, 5496, 256)])
+                                            (1, 16, 2748, 5496, 256), (1, 16, 4122, 4122, 512),
+                                            (1, 2, 300, 777, 512), (2, 3, 1374, 1374, 512), (1, 1, 40, 64, 512),
+                                            (1, 2, 1000, 65, 512)])
 def test_flash_attn_packed_qkv_layout(C, B, H, Nq, Nk, tile):
     """q,k,v read straight out of a [T, 3*C] qkv matrix (row stride 3C), o written as [T, C]."""
     Cdim = H * 64
