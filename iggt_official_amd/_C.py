@@ -31,6 +31,10 @@ _SIGNATURES = {
                               _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                               _c_int, _c_int, _c_int, _c_int, _c_float, _c_void_p],
     "iggt_im2row_patch14": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p],
+    "iggt_conv2d_nhwc_f32": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
+                             _c_int]
+                            + [_c_int] * 24 + [_c_void_p],
+    "iggt_bilinear_ac_nhwc_f32": [_c_void_p, _c_int, _c_void_p, _c_int] + [_c_int] * 6 + [_c_void_p] * 3,
     "iggt_write_special_tokens": [_c_void_p, _c_long, _c_long, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_void_p],
 }
@@ -171,3 +175,38 @@ def write_special_tokens(dst, src0, src1, S, nrows, row_off, first_view_is_zero)
                                           src1.data_ptr(), S, nrows, row_off, dst.shape[2],
                                           int(first_view_is_zero), _stream())
     _check(rc, "iggt_write_special_tokens")
+
+
+def conv2d_nhwc(x, w_hi, w_lo, bias, y, *, KH, KW, stride=1, pad_y=0, pad_x=0, Ho=None, Wo=None, res=None, res2=None,
+                relu_in=False, relu_res=False, act=0, prec=3, Cin=None, Cout=None, cout_phys=None, ps=1,
+                osy=1, osx=1, ooy=0, oox=0):
+    """x [N,Hi,Wi,ldx] fp32 NHWC, y [N,Hout,Wout,ldy] fp32 NHWC (see include/iggt_hip.h)."""
+    _dev(x, w_hi, w_lo, bias, y, res, res2)
+    assert x.dtype == torch.float32 and y.dtype == torch.float32 and x.stride(3) == 1 and y.stride(3) == 1
+    assert x.is_contiguous() and y.is_contiguous() and (res is None or res.is_contiguous())
+    N, Hi, Wi, ldx = x.shape
+    _, Hout, Wout, ldy = y.shape
+    Cin = ldx if Cin is None else Cin
+    Cout = w_hi.shape[0] if Cout is None else Cout
+    cout_phys = Cout if cout_phys is None else cout_phys
+    Ho = Hout if Ho is None else Ho
+    Wo = Wout if Wo is None else Wo
+    assert w_hi.dtype == torch.bfloat16 and w_hi.is_contiguous() and w_hi.shape[1] == KH * KW * Cin
+    rc = load().iggt_conv2d_nhwc_f32(x.data_ptr(), ldx, w_hi.data_ptr(), _ptr(w_lo), _ptr(bias), _ptr(res),
+                                     _ptr(res2), 0 if res is None else res.shape[3], y.data_ptr(), ldy, N, Hi, Wi, Cin, Ho, Wo,
+                                     Cout, KH, KW, stride, pad_y, pad_x, Hout, Wout, osy, osx, ooy, oox, cout_phys,
+                                     ps, int(relu_in), int(relu_res), act, prec, _stream())
+    _check(rc, "iggt_conv2d_nhwc_f32")
+    return y
+
+
+def bilinear_ac_nhwc(x, y, xpart=None, ypart=None):
+    """align_corners=True bilinear resize x [N,Hi,Wi,C] -> y [N,Ho,Wo,C] (fp32 NHWC), optional position map."""
+    _dev(x, y, xpart, ypart)
+    assert x.is_contiguous() and y.is_contiguous() and x.dtype == torch.float32
+    N, Hi, Wi, C = x.shape
+    _, Ho, Wo, _ = y.shape
+    rc = load().iggt_bilinear_ac_nhwc_f32(x.data_ptr(), C, y.data_ptr(), C, N, Hi, Wi, Ho, Wo, C, _ptr(xpart),
+                                          _ptr(ypart), _stream())
+    _check(rc, "iggt_bilinear_ac_nhwc_f32")
+    return y

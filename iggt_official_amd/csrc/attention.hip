@@ -27,34 +27,12 @@
 //  * exp2 domain: scores are scaled by scale*log2(e) inside one v_fma, v_exp_f32 directly.
 //  * grid is 1-D, XCD-chunked: all q-tiles of one (batch, head) are adjacent, so the workgroups that
 //    are co-resident on an XCD stream the same head's K/V through that XCD's L2.
-#include "common.h"
+#include "attention_common.h"
 #include "../../include/iggt_hip.h"
 
+using namespace iggt_attn;
+
 namespace {
-
-struct AttnParams {
-    const bf16_t* q;
-    const bf16_t* k;
-    const bf16_t* v;
-    bf16_t* o;
-    int B, H, Nq, Nk;
-    long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;  // in elements
-    float scale_log2;  // softmax scale * log2(e)
-    int qtiles;
-};
-
-constexpr int KV_TILE = 64;
-constexpr int K_BYTES = KV_TILE * 128;  // 8 KiB
-constexpr int BUF_BYTES = 2 * K_BYTES;  // K + V
-
-IGGT_DEVINL int v_lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 2)) << 5); }
-
-IGGT_DEVINL bf16x8 pack8(const f32x16& s, int base) {
-    bf16x8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)s[base + j];
-    return r;
-}
 
 template <int QB>
 __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(const AttnParams p) {
@@ -493,9 +471,11 @@ extern "C" int iggt_flash_attn_bf16_d64(const void* q, const void* k, const void
     p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.scale_log2 = scale * 1.4426950408889634f;
     if (q_rows_per_wg == 0) {
-        // pick the tile that wastes the fewest padded query rows; ties -> larger tile (more K/V reuse)
+        // pick the tile that wastes the fewest padded query rows; ties -> larger tile (more K/V reuse).
+        // Default kernel = v2 (staggered query blocks + deferred max, attention_v2.hip): measured
+        // 860 vs 805 TF/s on the 32-view global attention (profiles/r01_attn_variants.txt).
         const int pad256 = ((Nq + 255) / 256) * 256, pad128 = ((Nq + 127) / 128) * 128;
-        q_rows_per_wg = (pad256 <= pad128 + pad128 / 32) ? 256 : 128;
+        q_rows_per_wg = (pad256 <= pad128 + pad128 / 32) ? 1256 : 1128;
     }
     if (q_rows_per_wg == 256) {
         p.qtiles = (Nq + 255) / 256;
@@ -503,6 +483,8 @@ extern "C" int iggt_flash_attn_bf16_d64(const void* q, const void* k, const void
     } else if (q_rows_per_wg == 128) {
         p.qtiles = (Nq + 127) / 128;
         hipLaunchKernelGGL(flash_attn_d64_kernel<1>, dim3(B * H * p.qtiles), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (q_rows_per_wg == 1128 || q_rows_per_wg == 1256 || q_rows_per_wg == 2256 || q_rows_per_wg == 3256) {
+        iggt_launch_flash_attn_v2(p, q_rows_per_wg - 1000, (hipStream_t)stream);
     } else if (q_rows_per_wg == 512) {
         p.qtiles = (Nq + 511) / 512;
         hipLaunchKernelGGL(flash_attn_d64_pp_kernel<2>, dim3(B * H * p.qtiles), dim3(512), 0, (hipStream_t)stream, p);

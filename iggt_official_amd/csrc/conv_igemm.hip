@@ -1,0 +1,350 @@
+// Implicit-GEMM 2-D convolution on MFMA for the dense heads (DPT depth/point heads, SamProjector,
+// part head): NHWC fp32 activations in HBM, bf16 MFMA with fp32 accumulation, optional split-bf16
+// ("x3") operands for fp32-grade results.
+//
+// Replaces (reference file:line): every nn.Conv2d / nn.ConvTranspose2d of iggt/heads/dpt_head.py
+// (resize_layers 72-88, scratch.layerN_rn 345-357, ResidualConvUnit 369-411, FeatureFusionBlock.out_conv
+// 441-443,479, output_conv1/2 117-128), iggt/heads/adaptor.py Projects 9-35 + resize stacks 152-175 and
+// the 3x3 convs of iggt/heads/window_sa.py (CAB 40-47, conv_after_body/conv_before_upsample/conv_last
+// 383-391), which the reference runs in fp32 through cuDNN under autocast(enabled=False) (vggt.py:189).
+//
+// GEMM view:  Y[m][n] = sum_k A[m][k] W[n][k],  m = (img, oy, ox) output pixel, n = output channel,
+// k = (tap, c) with the tap major, so a 32-wide K chunk stays inside one tap and is a contiguous
+// 128-byte run of the NHWC input (zero-filled when the tap falls outside the image).
+//
+// Precision: the reference heads are fp32.  PREC=3 splits every operand into bf16 hi + bf16 lo
+// (x = hi + lo + O(2^-17 x)) and issues three MFMAs per product (hi*hi + hi*lo + lo*hi), i.e.
+// ~2^-16-relative products accumulated in fp32 -- fp32-grade results at 1/3 of the bf16 MFMA rate
+// (~5x the fp32-MFMA rate).  PREC=1 uses plain bf16 operands.  Activations are split on the fly in
+// the loader (fp32 -> hi/lo while staging to LDS); weights are pre-split once on the host side.
+//
+// Fused into the loader: ReLU on the input (ResidualConvUnit pre-activation).  Fused into the epilogue:
+// bias, ReLU / LeakyReLU(0.01) / exact GELU, residual add (optionally of the rectified residual -- the
+// reference's in-place-ReLU skip), and a generic output scatter
+//     out pixel = (oy * osy + ooy, ox * osx + oox), channel = n % cout_phys  with phase n / cout_phys
+// which implements ConvTranspose2d with kernel == stride as a 1x1 GEMM + pixel shuffle and
+// ConvTranspose2d(k4,s2,p1) as four 2x2 parity convolutions.
+//
+// Tiling: 128 x (32*WN*WAVES_N) output tile, BK = 32, 256 threads; LDS images [rows][32] bf16 with
+// the 16-B slot XOR ((row >> 2) & 3) (conflict-free ds_read_b128 for 64-byte rows), double-buffered,
+// register-staged one K-step ahead.
+#include "common.h"
+#include "../../include/iggt_hip.h"
+
+namespace {
+
+struct ConvParams {
+    const float* x;        // [Nimg][Hi][Wi][ldx] fp32, channels [0, Cin) used
+    const bf16_t* w_hi;    // [Cout][K] bf16, K = KH*KW*Cin (tap-major)
+    const bf16_t* w_lo;    // PREC == 3 only
+    const float* bias;     // [Cout] or null
+    const float* res;      // residual, same indexing as y (ldr channels stride), or null
+    const float* res2;     // second residual (never rectified), same layout as res, or null
+    float* y;              // [Nimg][Hout][Wout][ldy]
+    int Nimg, Hi, Wi, Cin, ldx;
+    int Ho, Wo;            // GEMM-row grid (number of kernel placements per image)
+    int Cout;              // GEMM N
+    int KH, KW, stride, pad_y, pad_x;
+    int Hout, Wout, ldy, ldr;
+    int osy, osx, ooy, oox;  // output scatter
+    int cout_phys;           // channels per output pixel (pixel-shuffle when Cout > cout_phys)
+    int ps;                  // pixel-shuffle factor (phase -> (phase / ps, phase % ps) added to the pixel)
+    int relu_in, relu_res, act;  // act: 0 none, 1 relu, 2 leaky 0.01, 3 gelu(erf)
+    int tiles_n;
+    long M;
+};
+
+constexpr int BK = 32;
+
+IGGT_DEVINL int slot_swz(int row, int slot) { return row * 64 + (((slot ^ (row >> 2)) & 3) << 4); }
+
+template <int PREC, int WM, int WN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int BM = 32 * WM * WAVES_M;
+    constexpr int BN = 32 * WN * WAVES_N;
+    static_assert(BM == 128 && WAVES_M * WAVES_N == 4, "256-thread tile");
+    constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64;
+    constexpr int STAGE = PREC * 0 + (PREC == 3 ? 2 : 1) * (A_BYTES + W_BYTES);
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = v / p.tiles_n, tn = v - tm * p.tiles_n;
+    const long m0 = (long)tm * BM;
+    const int n0 = tn * BN;
+
+    // ---- A loader: thread -> (row = tid/2, 16 channels = 64 B at half = tid&1) ---------------------
+    const int a_row = tid >> 1, a_half = tid & 1;
+    long am = m0 + a_row;
+    const bool a_ok = am < p.M;
+    if (!a_ok) am = p.M - 1;
+    const int hw = p.Ho * p.Wo;
+    const int a_img = (int)(am / hw);
+    const int a_rem = (int)(am - (long)a_img * hw);
+    const int a_oy = a_rem / p.Wo, a_ox = a_rem - a_oy * p.Wo;
+    const int iy0 = a_oy * p.stride - p.pad_y, ix0 = a_ox * p.stride - p.pad_x;
+    const float* a_base = p.x + ((long)a_img * p.Hi * p.Wi) * p.ldx + a_half * 16;
+    // ---- W loader: rows of 64 B (32 bf16); 256 threads x 16 B = 64 rows per pass ---------------------
+    constexpr int W_PASSES = BN / 64 > 0 ? BN / 64 : 1;
+    const int w_row = tid >> 2, w_piece = tid & 3;  // 4 x 16 B per row
+    const long Ktot = (long)p.KH * p.KW * p.Cin;
+    const int chunks_per_tap = p.Cin / BK;
+    const int KT = p.KH * p.KW * chunks_per_tap;
+
+    f32x4 ra[4];
+    u32x4 rwh[W_PASSES], rwl[W_PASSES];
+    auto gload = [&](int kt) {
+        const int tap = kt / chunks_per_tap, c0 = (kt - tap * chunks_per_tap) * BK;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const int iy = iy0 + ky, ix = ix0 + kx;
+        const bool ok = a_ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        const float* src = a_base + ((long)(ok ? iy : 0) * p.Wi + (ok ? ix : 0)) * p.ldx + c0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * i);
+            if (!ok) t = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.relu_in) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = fmaxf(t[e], 0.f);
+            }
+            ra[i] = t;
+        }
+#pragma unroll
+        for (int q = 0; q < W_PASSES; ++q) {
+            int r = n0 + w_row + 64 * q;
+            if (BN < 64 && w_row >= BN) r = n0;  // BN == 32: upper half of the threads duplicate row 0
+            r = r < p.Cout ? r : p.Cout - 1;
+            const long off = (long)r * Ktot + (long)kt * BK + w_piece * 8;
+            rwh[q] = *reinterpret_cast<const u32x4*>(p.w_hi + off);
+            if (PREC == 3) rwl[q] = *reinterpret_cast<const u32x4*>(p.w_lo + off);
+        }
+    };
+    auto swrite = [&](int buf) {
+        char* sAh = smem + buf * STAGE;
+        char* sWh = sAh + A_BYTES;
+        char* sAl = sWh + W_BYTES;  // PREC == 3 only
+        char* sWl = sAl + A_BYTES;
+        u32x4 h[2], l[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = ra[2 * i + (e >> 1)][2 * (e & 1)], x1 = ra[2 * i + (e >> 1)][2 * (e & 1) + 1];
+                const uint32_t hp = pack_bf16x2(x0, x1);
+                h[i][e] = hp;
+                if (PREC == 3) l[i][e] = pack_bf16x2(x0 - bf16_lo(hp), x1 - bf16_hi(hp));
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int off = slot_swz(a_row, a_half * 2 + i);
+            *reinterpret_cast<u32x4*>(sAh + off) = h[i];
+            if (PREC == 3) *reinterpret_cast<u32x4*>(sAl + off) = l[i];
+        }
+#pragma unroll
+        for (int q = 0; q < W_PASSES; ++q) {
+            const int r = w_row + 64 * q;
+            if (r < BN) {
+                const int off = slot_swz(r, w_piece);
+                *reinterpret_cast<u32x4*>(sWh + off) = rwh[q];
+                if (PREC == 3) *reinterpret_cast<u32x4*>(sWl + off) = rwl[q];
+            }
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) gload(kt + 1);
+        const char* sAh = smem + (kt & 1) * STAGE;
+        const char* sWh = sAh + A_BYTES;
+        const char* sAl = sWh + W_BYTES;
+        const char* sWl = sAl + A_BYTES;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const int off = slot_swz((wm * WM + i) * 32 + frow, 2 * kc + fhalf);
+                ah[i] = *reinterpret_cast<const bf16x8*>(sAh + off);
+                if (PREC == 3) al[i] = *reinterpret_cast<const bf16x8*>(sAl + off);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int off = slot_swz((wn * WN + j) * 32 + frow, 2 * kc + fhalf);
+                bh[j] = *reinterpret_cast<const bf16x8*>(sWh + off);
+                if (PREC == 3) bl[j] = *reinterpret_cast<const bf16x8*>(sWl + off);
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    if (PREC == 3) {  // small terms first
+                        acc[i][j] = mfma32(al[i], bh[j], acc[i][j]);
+                        acc[i][j] = mfma32(ah[i], bl[j], acc[i][j]);
+                    }
+                    acc[i][j] = mfma32(ah[i], bh[j], acc[i][j]);
+                }
+        }
+        if (kt + 1 < KT) swrite((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
+        if (n >= p.Cout) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        int co = n, py = 0, px = 0;
+        if (p.ps > 1) {
+            const int phase = n / p.cout_phys;
+            co = n - phase * p.cout_phys;
+            py = phase / p.ps;
+            px = phase - py * p.ps;
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = m0 + (wm * WM + i) * 32 + mfma32_row(r, lane);
+                if (m >= p.M) continue;
+                const int img = (int)(m / hw);
+                const int rem = (int)(m - (long)img * hw);
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                const long pix = ((long)img * p.Hout + oy * p.osy + p.ooy + py) * p.Wout + ox * p.osx + p.oox + px;
+                float val = acc[i][j][r] + bias;
+                if (p.act == 1) val = fmaxf(val, 0.f);
+                else if (p.act == 2) val = val > 0.f ? val : 0.01f * val;
+                else if (p.act == 3) val = 0.5f * val * (1.0f + erff(val * 0.70710678118654752440f));
+                if (p.res) {
+                    float rv = p.res[pix * p.ldr + co];
+                    if (p.relu_res) rv = fmaxf(rv, 0.f);
+                    val += rv;
+                    if (p.res2) val += p.res2[pix * p.ldr + co];
+                }
+                p.y[pix * p.ldy + co] = val;
+            }
+    }
+}
+
+template <int PREC, int WM, int WN, int WAVES_M, int WAVES_N>
+void launch(const ConvParams& p, hipStream_t st) {
+    constexpr int BN = 32 * WN * WAVES_N;
+    ConvParams q = p;
+    q.tiles_n = (p.Cout + BN - 1) / BN;
+    const long tiles_m = (p.M + 127) / 128;
+    hipLaunchKernelGGL((conv_igemm_kernel<PREC, WM, WN, WAVES_M, WAVES_N>), dim3((unsigned)(tiles_m * q.tiles_n)),
+                       dim3(256), 0, st, q);
+}
+
+}  // namespace
+
+extern "C" int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
+                                    const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg, int Hi, int Wi,
+                                    int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_y,
+                                    int pad_x, int Hout, int Wout, int osy, int osx, int ooy, int oox,
+                                    int cout_phys, int ps, int relu_in, int relu_res, int act, int prec,
+                                    void* stream) {
+    if (Nimg <= 0 || Cin <= 0 || (Cin % BK) != 0 || Cout <= 0 || KH <= 0 || KW <= 0) return -1;
+    if ((ldx % 4) != 0 || ldx < Cin) return -2;
+    if (prec != 1 && prec != 3) return -3;
+    if (prec == 3 && w_lo == nullptr) return -3;
+    if (res2 && !res) return -5;
+    if (ps < 1 || cout_phys <= 0 || (ps > 1 && Cout != cout_phys * ps * ps)) return -4;
+    ConvParams p;
+    p.x = x; p.w_hi = (const bf16_t*)w_hi; p.w_lo = (const bf16_t*)w_lo; p.bias = bias; p.res = res; p.res2 = res2; p.y = y;
+    p.Nimg = Nimg; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.ldx = ldx; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
+    p.KH = KH; p.KW = KW; p.stride = stride; p.pad_y = pad_y; p.pad_x = pad_x;
+    p.Hout = Hout; p.Wout = Wout; p.ldy = ldy; p.ldr = ldr;
+    p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox; p.cout_phys = cout_phys; p.ps = ps;
+    p.relu_in = relu_in; p.relu_res = relu_res; p.act = act;
+    p.M = (long)Nimg * Ho * Wo;
+    p.tiles_n = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (prec == 3) {
+        if (Cout > 64) launch<3, 2, 2, 2, 2>(p, st);
+        else if (Cout > 32) launch<3, 1, 2, 4, 1>(p, st);
+        else launch<3, 1, 1, 4, 1>(p, st);
+    } else {
+        if (Cout > 64) launch<1, 2, 2, 2, 2>(p, st);
+        else if (Cout > 32) launch<1, 1, 2, 4, 1>(p, st);
+        else launch<1, 1, 1, 4, 1>(p, st);
+    }
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bilinear resize, align_corners=True, NHWC fp32 (reference: custom_interpolate, dpt_head.py:484-509,
+// used by FeatureFusionBlock 471-478 and the head tails 251-256 / part_head.py 228-238).
+// Optional separable additive position map (xpart [Wo][C/2] | ypart [Ho][C/2]) fused in.
+namespace {
+struct ResizeParams {
+    const float* x; float* y;
+    int N, Hi, Wi, Ho, Wo, C, ldx, ldy;
+    float sy, sx;
+    const float* xpart; const float* ypart;  // optional
+};
+
+__global__ __launch_bounds__(256) void bilinear_ac_nhwc_kernel(const ResizeParams p) {
+    const int c4n = p.C / 4;
+    const long total = (long)p.N * p.Ho * p.Wo * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        long r = i / c4n;
+        const int ox = (int)(r % p.Wo);
+        r /= p.Wo;
+        const int oy = (int)(r % p.Ho);
+        const int n = (int)(r / p.Ho);
+        // PyTorch upsample_bilinear2d (align_corners): src = dst * (in-1)/(out-1), lambda from the floor
+        const float fy = oy * p.sy, fx = ox * p.sx;
+        int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < p.Hi - 1 ? 1 : 0), x1 = x0 + (x0 < p.Wi - 1 ? 1 : 0);
+        const float ly = fy - y0, lx = fx - x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* b = p.x + (long)n * p.Hi * p.Wi * p.ldx + c4 * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((long)y0 * p.Wi + x0) * p.ldx);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((long)y0 * p.Wi + x1) * p.ldx);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((long)y1 * p.Wi + x0) * p.ldx);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((long)y1 * p.Wi + x1) * p.ldx);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+        if (p.xpart) {
+            const int c = c4 * 4, half = p.C / 2;
+            const float* t = (c < half) ? (p.xpart + (long)ox * half + c) : (p.ypart + (long)oy * half + (c - half));
+            const f32x4 a = *reinterpret_cast<const f32x4*>(t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += a[e];
+        }
+        *reinterpret_cast<f32x4*>(p.y + (((long)n * p.Ho + oy) * p.Wo + ox) * p.ldy + c4 * 4) = o;
+    }
+}
+}  // namespace
+
+extern "C" int iggt_bilinear_ac_nhwc_f32(const float* x, int ldx, float* y, int ldy, int N, int Hi, int Wi, int Ho,
+                                         int Wo, int C, const float* xpart, const float* ypart, void* stream) {
+    if (N <= 0 || (C % 8) != 0 || (ldx % 4) || (ldy % 4)) return -1;
+    ResizeParams p;
+    p.x = x; p.y = y; p.N = N; p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.C = C; p.ldx = ldx; p.ldy = ldy;
+    p.sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+    p.sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    p.xpart = xpart; p.ypart = ypart;
+    const long total = (long)N * Ho * Wo * (C / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(bilinear_ac_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}

@@ -4,18 +4,21 @@ State-dict layout is the reference's (`norm`, `projects.{0..3}`, `resize_layers.
 `scratch.layer{1..4}_rn`, `scratch.refinenet{1..4}.{out_conv,resConfUnit{1,2}.conv{1,2}}`,
 `scratch.output_conv1`, `scratch.output_conv2.{0,2}`).
 
-Execution on the MI355X (round 1 state):
-  * token stage in HIP: LayerNorm(2048) over the [frame|global] token halves with the 5 special
-    tokens skipped by row remap, then the 1x1 "projects" conv as a bf16 MFMA GEMM whose epilogue adds
-    the bias and the (input-independent, cached) UV sin/cos position map -- one pass, NHWC output;
-  * the convolutional pyramid (3x3 / transposed convs, bilinear align_corners resizes) runs through
-    PyTorch-ROCm (MIOpen) in fp32 exactly as the reference does under `autocast(enabled=False)`
-    (vggt.py:189); DESIGN.md lists it as the next kernel family to move to hand-written HIP.
-Frames are independent in every head op (BatchNorm-free, per-frame convs: SURVEY.md section 0
-fact 6), so `frames_chunk_size` only bounds memory; the result is identical for any chunking
-(the reference's own chunked branch is broken for S > 12, appendix D.1).
+Execution on the MI355X -- everything NHWC fp32 in HBM, all GEMM-shaped work on MFMA:
+  * token stage: LayerNorm(2048) over the [frame|global] halves with the 5 special tokens skipped by row
+    remap (csrc/elementwise.hip), then the 1x1 `projects` conv as a bf16 MFMA GEMM whose epilogue adds the
+    bias and the cached UV sin/cos position map (csrc/gemm_bf16.hip) -> NHWC directly;
+  * every Conv2d / ConvTranspose2d runs on the implicit-GEMM kernel (csrc/conv_igemm.hip) with split-bf16
+    operands (fp32-grade, the reference runs the heads in fp32: vggt.py:189): transposed convs with
+    kernel == stride are 1x1 GEMMs with a pixel-shuffle epilogue; ResidualConvUnit is two launches
+    (ReLU-on-load -> conv -> ReLU, then conv + rectified-input skip [+ the fusion add]);
+  * bilinear align_corners resizes (+ the full-resolution position map) are one HBM-bound kernel;
+  * tail: conv3x3(128->32)+ReLU on MFMA; the 32->{4,2} 1x1 and the exp/expm1 activations are a few
+    PyTorch-ROCm elementwise ops on [S,H,W,4].
+Frames are independent in every head op, so `frames_chunk_size` only bounds
+memory; results do not depend on it (the reference's own chunked branch is broken for S > 12, App. D.1).
 """
-from typing import List, Tuple
+from typing import List
 
 import torch
 import torch.nn as nn
@@ -23,11 +26,13 @@ import torch.nn.functional as F
 
 from .. import _C
 from ..layers.blocks import Workspace
-from .head_act import activate_head
-from .utils import pos_embed_map, pos_embed_xy
+from . import convops as co
+from .head_act import inverse_log_transform
+from .utils import pos_embed_map, pos_embed_rows
 
 
 def custom_interpolate(x, size=None, scale_factor=None, mode="bilinear", align_corners=True):
+    """NCHW torch version kept for API parity (reference dpt_head.py:484-509)."""
     if size is None:
         size = (int(x.shape[-2] * scale_factor), int(x.shape[-1] * scale_factor))
     return F.interpolate(x, size=size, mode=mode, align_corners=align_corners)
@@ -44,10 +49,14 @@ class ResidualConvUnit(nn.Module):
         self.conv2 = nn.Conv2d(features, features, 3, 1, 1, bias=True, groups=groups)
         self.norm1 = None
         self.norm2 = None
+        self._pk = co.PackCache()
 
-    def forward(self, x):
-        r = F.relu(x)
-        return self.conv2(F.relu(self.conv1(r))) + r
+    def forward_nhwc(self, x, extra=None):
+        """x NHWC -> conv2(relu(conv1(relu x))) + relu(x) (+ extra)."""
+        p1 = self._pk.get(1, (self.conv1.weight, self.conv1.bias), lambda: co.pack_conv2d(self.conv1))
+        p2 = self._pk.get(2, (self.conv2.weight, self.conv2.bias), lambda: co.pack_conv2d(self.conv2))
+        t = co.run(p1, x, relu_in=True, act=1)
+        return co.run(p2, t, res=x, relu_res=True, res2=extra)
 
 
 class FeatureFusionBlock(nn.Module):
@@ -62,18 +71,19 @@ class FeatureFusionBlock(nn.Module):
         self.has_residual = has_residual
         self.resConfUnit2 = ResidualConvUnit(features, activation, bn, groups=groups)
         self.size = size
+        self._pk = co.PackCache()
 
-    def forward(self, *xs, size=None):
-        y = xs[0]
+    def forward_nhwc(self, x0, x1=None, size=None):
+        """reference FeatureFusionBlock.forward (dpt_head.py:455-481) on NHWC tensors."""
+        y = x0
         if self.has_residual:
-            y = y + self.resConfUnit1(xs[1])
-        y = self.resConfUnit2(y)
-        if size is None and self.size is None:
-            y = custom_interpolate(y, scale_factor=2, align_corners=self.align_corners)
-        else:
-            y = custom_interpolate(y, size=size if size is not None else self.size,
-                                   align_corners=self.align_corners)
-        return self.out_conv(y)
+            y = self.resConfUnit1.forward_nhwc(x1, extra=x0)      # x0 + rcu1(x1), the add is fused
+        y = self.resConfUnit2.forward_nhwc(y)
+        if size is None:
+            size = self.size if self.size is not None else (2 * y.shape[1], 2 * y.shape[2])
+        y = co.resize(y, tuple(size))
+        pc = self._pk.get(0, (self.out_conv.weight, self.out_conv.bias), lambda: co.pack_conv2d(self.out_conv))
+        return co.run(pc, y)
 
 
 def _make_fusion_block(features, size=None, has_residual=True, groups=1):
@@ -105,7 +115,7 @@ class TokenProjector:
         return self._pk[idx][1:]
 
     def __call__(self, tokens, s0, s1, psi, gh, gw, norm: nn.LayerNorm, idx, conv: nn.Conv2d, pos_table=None):
-        """tokens [1, S_all, P, 2C] fp32 -> NCHW-viewed (channels-last memory) [S, oc, gh, gw] fp32."""
+        """tokens [1, S_all, P, 2C] fp32 -> NHWC [S, gh, gw, oc] fp32."""
         if not tokens.is_cuda:
             raise _C.HipExtensionError("head token projection runs on HIP kernels only")
         _, S_all, P, C2 = tokens.shape
@@ -118,7 +128,7 @@ class TokenProjector:
         w, b = self.packed(idx, conv)
         out = torch.empty(S * g2, w.shape[0], dtype=torch.float32, device=tokens.device)
         _C.gemm_bf16(xn, w, out, bias=b, add_table=pos_table, rows_in=g2, rows_out=g2, row_off=0)
-        return out.view(S, gh, gw, w.shape[0]).permute(0, 3, 1, 2)
+        return out.view(S, gh, gw, w.shape[0])
 
 
 class DPTHead(nn.Module):
@@ -156,15 +166,20 @@ class DPTHead(nn.Module):
             self.scratch.output_conv2 = nn.Sequential(nn.Conv2d(h1 // 2, h2, 3, 1, 1), nn.ReLU(inplace=True),
                                                       nn.Conv2d(h2, output_dim, 1, 1, 0))
         self._tp = TokenProjector()
+        self._pk = co.PackCache()
 
     # ------------------------------------------------------------------------------------------
+    def _conv(self, key, conv):
+        return self._pk.get(key, (conv.weight, conv.bias), lambda: co.pack_conv2d(conv))
+
     def forward(self, aggregated_tokens_list, images, patch_start_idx, frames_chunk_size=8):
+        """Returns (preds [1,S,H,W,c], conf [1,S,H,W][, (out2,out3,out4) NHWC fusion features])."""
         B, S, _, H, W = images.shape
         if B != 1:
             raise NotImplementedError("heads run one scene (B=1) at a time, as demo.py does")
         chunk = S if (frames_chunk_size is None or frames_chunk_size >= S) else frames_chunk_size
         assert chunk > 0
-        parts = [self._forward_impl(aggregated_tokens_list, images, patch_start_idx, s0, min(s0 + chunk, S))
+        parts = [self._forward_impl(aggregated_tokens_list, H, W, patch_start_idx, s0, min(s0 + chunk, S))
                  for s0 in range(0, S, chunk)]
         if len(parts) == 1:
             return parts[0]
@@ -176,42 +191,76 @@ class DPTHead(nn.Module):
         return tuple(merged)
 
     def _token_maps(self, tokens_list, psi, s0, s1, H, W):
+        """projects -> (+pos) -> resize_layers, NHWC (reference dpt_head.py:225-244)."""
         gh, gw = H // self.patch_size, W // self.patch_size
         maps = []
         for i, li in enumerate(self.intermediate_layer_idx):
             conv = self.projects[i]
             pos = pos_embed_map(conv.out_channels, gh, gw, W, H, tokens_list[li].device) if self.pos_embed else None
             x = self._tp(tokens_list[li], s0, s1, psi, gh, gw, self.norm, i, conv, pos)
-            maps.append(self.resize_layers[i](x))
+            rl = self.resize_layers[i]
+            if isinstance(rl, nn.ConvTranspose2d):
+                pc = self._pk.get(("rl", i), (rl.weight, rl.bias), lambda rl=rl: co.pack_convT_kernel_eq_stride(rl))
+                x = co.run(pc, x)
+            elif isinstance(rl, nn.Conv2d):
+                x = co.run(self._conv(("rl", i), rl), x)
+            maps.append(x)
         return maps
 
-    def _forward_impl(self, tokens_list, images, psi, s0, s1):
-        _, _, _, H, W = images.shape
+    def _forward_impl(self, tokens_list, H, W, psi, s0, s1):
         S = s1 - s0
         gh, gw = H // self.patch_size, W // self.patch_size
         maps = self._token_maps(tokens_list, psi, s0, s1, H, W)
         out, side = self.scratch_forward(maps)
-        out = custom_interpolate(out, (int(gh * self.patch_size / self.down_ratio),
-                                       int(gw * self.patch_size / self.down_ratio)))
+        size = (int(gh * self.patch_size / self.down_ratio), int(gw * self.patch_size / self.down_ratio))
         if self.pos_embed:
-            xp, yp = pos_embed_xy(out.shape[1], out.shape[2], out.shape[3], W, H, out.device)
-            half = out.shape[1] // 2
-            out[:, :half] += xp
-            out[:, half:] += yp
+            xr, yr = pos_embed_rows(out.shape[3], size[0], size[1], W, H, out.device)
+            out = co.resize(out, size, xr, yr)      # bilinear + position map in one pass
+        else:
+            out = co.resize(out, size)
         if self.for_tracker:
-            return out.view(1, S, *out.shape[1:])
-        out = self.scratch.output_conv2(out)
-        preds, conf = activate_head(out, activation=self.activation, conf_activation=self.conf_activation)
+            return out.permute(0, 3, 1, 2)[None]
+        c2 = self.scratch.output_conv2
+        out = co.run(self._conv("oc2_0", c2[0]), out, act=1)                 # conv3x3 128->32 + ReLU
+        out = F.linear(out, c2[2].weight.view(c2[2].out_channels, -1), c2[2].bias)   # 1x1, 32 -> 4|2 (NHWC)
+        preds, conf = self._activate(out)
         preds = preds.reshape(1, S, *preds.shape[1:])
         conf = conf.reshape(1, S, *conf.shape[1:])
         return (preds, conf, side) if self.use_point_feat else (preds, conf)
 
+    def _activate(self, fmap):
+        """activate_head (reference head_act.py:61-125) on an NHWC map."""
+        xyz, conf = fmap[..., :-1], fmap[..., -1]
+        if self.activation == "inv_log":
+            pts = inverse_log_transform(xyz)
+        elif self.activation == "exp":
+            pts = torch.exp(xyz)
+        elif self.activation == "relu":
+            pts = F.relu(xyz)
+        elif self.activation == "linear":
+            pts = xyz
+        elif self.activation == "norm":
+            pts = xyz / xyz.norm(dim=-1, keepdim=True)
+        elif self.activation == "sigmoid":
+            pts = torch.sigmoid(xyz)
+        else:
+            raise ValueError(f"Unknown activation: {self.activation}")
+        if self.conf_activation == "expp1":
+            c = 1 + conf.exp()
+        elif self.conf_activation == "expp0":
+            c = conf.exp()
+        elif self.conf_activation == "sigmoid":
+            c = torch.sigmoid(conf)
+        else:
+            raise ValueError(f"Unknown conf_activation: {self.conf_activation}")
+        return pts.contiguous(), c.contiguous()
+
     def scratch_forward(self, features: List[torch.Tensor]):
-        l1, l2, l3, l4 = features
+        """reference dpt_head.py:286-316 on NHWC maps -> (output_conv1 map, (out2, out3, out4))."""
         sc = self.scratch
-        r1, r2, r3, r4 = sc.layer1_rn(l1), sc.layer2_rn(l2), sc.layer3_rn(l3), sc.layer4_rn(l4)
-        out4 = sc.refinenet4(r4, size=r3.shape[2:])
-        out3 = sc.refinenet3(out4, r3, size=r2.shape[2:])
-        out2 = sc.refinenet2(out3, r2, size=r1.shape[2:])
-        out1 = sc.refinenet1(out2, r1)
-        return sc.output_conv1(out1), (out2, out3, out4)
+        r = [co.run(self._conv(("rn", i), getattr(sc, f"layer{i + 1}_rn")), features[i]) for i in range(4)]
+        out4 = sc.refinenet4.forward_nhwc(r[3], size=r[2].shape[1:3])
+        out3 = sc.refinenet3.forward_nhwc(out4, r[2], size=r[1].shape[1:3])
+        out2 = sc.refinenet2.forward_nhwc(out3, r[1], size=r[0].shape[1:3])
+        out1 = sc.refinenet1.forward_nhwc(out2, r[0])
+        return co.run(self._conv("oc1", sc.output_conv1), out1), (out2, out3, out4)

@@ -7,6 +7,8 @@ the point head's fusion features (out2 @4g, out3 @2g, out4 @g):
   -> refinenet1 -> output_conv1 (128 ch @8g) -> SwinSA window self-attention (222-225)
   -> bilinear(align_corners) to HxW -> conv3x3 -> ReLU -> conv1x1 -> [B,S,8,H,W], NO activation
   (240-243; the ctor's activation="norm" is never applied).
+All maps are NHWC fp32; convolutions / resizes run on the HIP kernels (conv_igemm.hip), the attention
+cores (head dim 32) on PyTorch-ROCm SDPA in fp32.
 Reference quirks kept: `cross_attention_1` is evaluated by the reference but its result is dead
 (part_head.py:178-185, appendix D.3) -- its parameters exist for checkpoint loading, the compute is
 skipped; PartHead inherits DPTHead.__init__ so unused `norm/projects/resize_layers` parameters
@@ -16,10 +18,17 @@ from typing import List
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from . import convops as co
 from .block import MemEffCrossAttention
-from .dpt_head import DPTHead, _make_fusion_block, _make_scratch, custom_interpolate
+from .dpt_head import DPTHead, _make_fusion_block, _make_scratch
 from .window_sa import SwinCA, SwinSA
+
+
+def _nhwc(t):
+    """Accept NCHW-shaped tensors (reference layout; channels-last views are free) -> contiguous NHWC."""
+    return t.permute(0, 2, 3, 1).contiguous()
 
 
 class PartHead(DPTHead):
@@ -52,7 +61,8 @@ class PartHead(DPTHead):
 
     def forward(self, aggregated_tokens_list: List[torch.Tensor], images, patch_start_idx, frames_chunk_size=8,
                 point_feature=None):
-        """aggregated_tokens_list: the 4 SamProjector maps [S, 256, ., .]; point_feature: (out2, out3, out4)."""
+        """aggregated_tokens_list: the 4 SamProjector maps [S, 256, ., .] (NCHW-shaped);
+        point_feature: (out2, out3, out4) NHWC maps of the point head."""
         B, S, _, H, W = images.shape
         if H % 28 or W % 28:
             raise ValueError(f"part_feat needs H and W to be multiples of 28 (got {H}x{W}): the 4g / 8g maps "
@@ -61,37 +71,32 @@ class PartHead(DPTHead):
         outs = []
         for s0 in range(0, S, chunk):
             s1 = min(s0 + chunk, S)
-            maps = [m[s0:s1] for m in aggregated_tokens_list]
-            pf = None if point_feature is None else [p[s0:s1] for p in point_feature]
+            maps = [_nhwc(m[s0:s1]) for m in aggregated_tokens_list]
+            pf = None if point_feature is None else [p[s0:s1].contiguous() for p in point_feature]
             outs.append(self._part_impl(maps, H, W, pf))
         out = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
         return out.view(B, S, *out.shape[1:])
 
     def _fuse(self, features, point_feat):
-        l1, l2, l3, l4 = features
         sc = self.scratch
-        r1, r2, r3, r4 = sc.layer1_rn(l1), sc.layer2_rn(l2), sc.layer3_rn(l3), sc.layer4_rn(l4)
-        out = sc.refinenet4(r4, size=r3.shape[2:])
+        r = [co.run(self._conv(("rn", i), getattr(sc, f"layer{i + 1}_rn")), features[i]) for i in range(4)]
+        out = sc.refinenet4.forward_nhwc(r[3], size=r[2].shape[1:3])
         if point_feat is not None:
-            q = out.flatten(2).transpose(1, 2)
-            kv = point_feat[2].flatten(2).transpose(1, 2)
-            out4 = self.cross_attention_2(q, kv, kv).transpose(1, 2).reshape(out.shape)
-        else:
-            out4 = out
-        out = sc.refinenet3(out4, r3, size=r2.shape[2:])
-        out = sc.refinenet2(out, r2, size=r1.shape[2:])
+            n, h, w, c = out.shape
+            kv = point_feat[2].reshape(n, -1, c)
+            out = self.cross_attention_2(out.reshape(n, h * w, c), kv, kv).reshape(n, h, w, c)
+        out = sc.refinenet3.forward_nhwc(out, r[2], size=r[1].shape[1:3])
+        out = sc.refinenet2.forward_nhwc(out, r[1], size=r[0].shape[1:3])
         if point_feat is not None:
-            out2 = self.window_cross_attention(out.permute(0, 2, 3, 1), point_feat[0].permute(0, 2, 3, 1),
-                                               point_feat[0].permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
-        else:
-            out2 = out
-        out = sc.refinenet1(out2, r1)
-        return sc.output_conv1(out)
+            out = self.window_cross_attention(out, point_feat[0], point_feat[0])
+        out = sc.refinenet1.forward_nhwc(out, r[0])
+        return co.run(self._conv("oc1", sc.output_conv1), out)
 
     def _part_impl(self, maps, H, W, point_feat):
         gh, gw = H // self.patch_size, W // self.patch_size
-        out = self._fuse(maps, point_feat)
-        out = self.window_self_atten(out.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2).contiguous()
-        out = custom_interpolate(out, (int(gh * self.patch_size / self.down_ratio),
-                                       int(gw * self.patch_size / self.down_ratio)))
-        return self.scratch.output_conv2(out)
+        out = self.window_self_atten(self._fuse(maps, point_feat))
+        out = co.resize(out, (int(gh * self.patch_size / self.down_ratio), int(gw * self.patch_size / self.down_ratio)))
+        c2 = self.scratch.output_conv2
+        out = co.run(self._conv("oc2_0", c2[0]), out, act=1)
+        out = F.linear(out, c2[2].weight.view(c2[2].out_channels, -1), c2[2].bias)      # NHWC [S,H,W,8]
+        return out.permute(0, 3, 1, 2).contiguous()                                         # reference: [S,8,H,W]

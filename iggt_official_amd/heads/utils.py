@@ -58,3 +58,12 @@ def pos_embed_xy(C: int, h: int, w: int, W: int, H: int, device, ratio: float = 
         yp = (torch.cat([torch.sin(ay), torch.cos(ay)], 1).float() * ratio).t().reshape(1, 2 * q, h, 1)
         _CACHE[key] = (xp.contiguous().to(device), yp.contiguous().to(device))
     return _CACHE[key]
+
+
+def pos_embed_rows(C: int, h: int, w: int, W: int, H: int, device, ratio: float = 0.1):
+    """Separable form for the NHWC resize kernel: (xrows [w, C/2], yrows [h, C/2]) fp32 contiguous."""
+    key = ("rows", C, h, w, W, H, str(device), ratio)
+    if key not in _CACHE:
+        xp, yp = pos_embed_xy(C, h, w, W, H, device, ratio)
+        _CACHE[key] = (xp[0, :, 0, :].t().contiguous(), yp[0, :, :, 0].t().contiguous())
+    return _CACHE[key]

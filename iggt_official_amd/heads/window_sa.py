@@ -12,12 +12,15 @@ Two reference behaviours are reproduced on purpose because trained weights depen
     permutation (appendix D.4);
   * map sizes must be multiples of the window (8): the reference fails in calculate_mask
     (window_sa.py:401-415); here a ValueError states the constraint.
-Round-1 execution: PyTorch-ROCm fp32 ops on the GPU (next to move to HIP).
+Execution: NHWC fp32; every 3x3 convolution (CAB, conv_after_body, conv_before_upsample, conv_last) runs on
+the implicit-GEMM MFMA kernel (csrc/conv_igemm.hip; CAB's 42-channel bottleneck is zero-padded to 64); the
+window attention cores (head dim 32) and the small Linear/LayerNorm layers run on PyTorch-ROCm fp32 ops.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import convops as co
 from .block import MemEffAttention
 
 
@@ -57,8 +60,24 @@ class CAB(nn.Module):
                                  nn.Conv2d(num_feat // compress_ratio, num_feat, 3, 1, 1),
                                  ChannelAttention(num_feat, squeeze_factor))
 
+        self._pk = co.PackCache()
+
     def forward(self, x):
         return self.cab(x)
+
+    def forward_nhwc(self, x):
+        """conv3x3 -> GELU -> conv3x3 -> channel attention (global average pool per frame), NHWC."""
+        c0, c2, ca = self.cab[0], self.cab[2], self.cab[3].attention
+        mid = c0.out_channels
+        mid_pad = (mid + 31) // 32 * 32
+        p0 = self._pk.get(0, (c0.weight, c0.bias), lambda: co.pack_conv2d(c0))
+        p2 = self._pk.get(2, (c2.weight, c2.bias), lambda: co.pack_conv2d(c2, cin_pad=mid_pad))
+        t = co.run(p0, x, act=3, ldy=mid_pad)           # GELU fused; channels [mid, mid_pad) stay zero
+        y = co.run(p2, t)
+        g = y.mean(dim=(1, 2))                           # AdaptiveAvgPool2d(1) over the whole frame
+        g = F.relu(F.linear(g, ca[1].weight.flatten(1), ca[1].bias))
+        g = torch.sigmoid(F.linear(g, ca[3].weight.flatten(1), ca[3].bias))
+        return y * g[:, None, None, :]
 
 
 class Mlp(nn.Module):
@@ -102,7 +121,7 @@ class HAB(nn.Module):
         b, _, c = x.shape
         ws = self.window_size
         y = self.norm1(x).view(b, h, w, c)
-        conv_x = self.conv_block(y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).reshape(b, h * w, c)
+        conv_x = self.conv_block.forward_nhwc(y.contiguous()).reshape(b, h * w, c)
         win = window_partition(y, ws).view(-1, ws * ws, c)
         att = window_reverse(self.attn(win).view(-1, ws, ws, c), ws, h, w).view(b, h * w, c)
         x = x + att + conv_x * self.conv_scale
@@ -189,16 +208,24 @@ class SwinSA(nn.Module):
         return rel.sum(-1)
 
     def _tail(self, body, x):
-        x = self.conv_after_body(body) + x
-        return self.conv_last(self.conv_before_upsample(x)).permute(0, 2, 3, 1).contiguous()
+        """conv_after_body(body) + x -> conv3x3 -> LeakyReLU(0.01) -> conv3x3, all NHWC on the HIP conv kernel."""
+        if not hasattr(self, "_pk"):
+            self._pk = co.PackCache()
+        cab, cbu, cl = self.conv_after_body, self.conv_before_upsample[0], self.conv_last
+        p0 = self._pk.get(0, (cab.weight, cab.bias), lambda: co.pack_conv2d(cab))
+        p1 = self._pk.get(1, (cbu.weight, cbu.bias), lambda: co.pack_conv2d(cbu))
+        p2 = self._pk.get(2, (cl.weight, cl.bias), lambda: co.pack_conv2d(cl))
+        y = co.run(p0, body, res=x)
+        y = co.run(p1, y, act=2)
+        return co.run(p2, y)
 
     def forward(self, x):
         """x NHWC -> NHWC."""
-        x = x.permute(0, 3, 1, 2)
-        b, c, h, w = x.shape
+        x = x.contiguous()
+        b, h, w, c = x.shape
         _check_window_grid(h, w, self.window_size)
-        t = self.atten_block(self.patch_embed(x), (h, w))
-        body = self.norm(t).transpose(1, 2).reshape(b, c, h, w)
+        t = self.atten_block(self.patch_embed.norm(x.view(b, h * w, c)), (h, w))
+        body = self.norm(t).view(b, h, w, c)
         return self._tail(body, x)
 
 
@@ -228,10 +255,11 @@ class SwinCA(SwinSA):
         return rel.sum(-1)
 
     def forward(self, x, k, v):
-        x, k, v = (t.permute(0, 3, 1, 2) for t in (x, k, v))
-        b, c, h, w = x.shape
+        """x, k, v NHWC -> NHWC."""
+        x = x.contiguous()
+        b, h, w, c = x.shape
         _check_window_grid(h, w, self.window_size)
-        t = self.atten_block(self.patch_embed(x), self.patch_embed(k), self.patch_embed(v), (h, w),
-                             self.relative_position_index_OCA)
-        body = self.norm(t).transpose(1, 2).reshape(b, c, h, w)
+        tn = lambda z: self.patch_embed.norm(z.reshape(b, h * w, c))  # noqa: E731
+        t = self.atten_block(tn(x), tn(k), tn(v), (h, w), self.relative_position_index_OCA)
+        body = self.norm(t).view(b, h, w, c)
         return self._tail(body, x)

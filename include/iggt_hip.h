@@ -70,10 +70,26 @@ int iggt_write_special_tokens(float* dst, long view_stride, long ldd, const floa
                               const float* src1, int S, int nrows, int row_off, int C,
                               int first_view_is_zero, void* stream);
 
-/* Fused DPT tail: per output pixel (y,x) of an H x W map
- *   f = bilinear_align_corners(feat[s] (hf x wf x 128, NHWC fp32)) + pos_embed(y,x) ; conv3x3 128->32, ReLU,
- *   conv1x1 32->nout, activation -> preds [S][H][W][nout-1], conf [S][H][W].
- * See csrc/dpt_tail.hip.  Replaces iggt/heads/dpt_head.py:251-265 + iggt/heads/head_act.py:61-125. */
+/* Implicit-GEMM convolution on MFMA, NHWC fp32 in/out, bf16 (prec 1) or split-bf16 hi+lo (prec 3, fp32-grade)
+ * operands with fp32 accumulate.  w_hi/w_lo: bf16 [Cout][KH*KW*Cin] tap-major.  GEMM rows = (img, oy, ox) over an
+ * Ho x Wo placement grid; input pixel = (oy*stride - pad_y + ky, ox*stride - pad_x + kx); output pixel =
+ * (oy*osy + ooy + py, ox*osx + oox + px) in an Hout x Wout map, where (py, px) = phase of n / cout_phys when
+ * ps > 1 (pixel shuffle: ConvTranspose2d with kernel == stride).  relu_in: ReLU on loaded inputs; res: residual
+ * added after the activation (relu_res: add max(res,0)); res2: optional second residual (plain add); act: 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 GELU(erf).
+ * Replaces the nn.Conv2d / nn.ConvTranspose2d of iggt/heads/dpt_head.py:72-128,345-411,441-479,
+ * iggt/heads/adaptor.py:9-35,152-175 and iggt/heads/window_sa.py:40-47,383-391. */
+int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
+                         const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg, int Hi, int Wi,
+                         int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_y,
+                         int pad_x, int Hout, int Wout, int osy, int osx, int ooy, int oox,
+                         int cout_phys, int ps, int relu_in, int relu_res, int act, int prec,
+                         void* stream);
+
+/* Bilinear resize with align_corners=True, NHWC fp32, optional separable additive position map
+ * (xpart [Wo][C/2] for channels [0,C/2), ypart [Ho][C/2] for [C/2,C)).
+ * Replaces custom_interpolate (iggt/heads/dpt_head.py:484-509) and _apply_pos_embed (dpt_head.py:274-284). */
+int iggt_bilinear_ac_nhwc_f32(const float* x, int ldx, float* y, int ldy, int N, int Hi, int Wi, int Ho,
+                              int Wo, int C, const float* xpart, const float* ypart, void* stream);
 
 #ifdef __cplusplus
 }

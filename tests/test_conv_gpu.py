@@ -1,0 +1,115 @@
+"""Implicit-GEMM convolution / resize kernels (GPU) vs PyTorch fp64 references.
+
+prec=3 (split-bf16 hi+lo, what the heads use) must be fp32-grade: 2e-5 of the output range.
+prec=1 (plain bf16 operands) is gated at the bf16 rounding budget (1e-2 max, 4e-3 l2)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from conftest import report
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max()), float((a - b).norm() / b.norm())
+
+
+def _mk(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,hw", [(256, 256, 3, 1, 1, (37, 41)), (1024, 256, 3, 1, 1, (19, 19)),
+                                                      (1024, 1024, 3, 2, 1, (37, 37)), (256, 256, 1, 1, 0, (30, 50)),
+                                                      (256, 128, 3, 1, 1, (24, 40)), (128, 32, 3, 1, 1, (56, 70)),
+                                                      (128, 64, 3, 1, 1, (16, 24)), (64, 128, 3, 1, 1, (16, 24))])
+@pytest.mark.parametrize("prec", [3, 1])
+def test_conv2d_vs_torch(cin, cout, k, stride, pad, hw, prec):
+    from iggt_official_amd.heads import convops as co
+
+    conv = nn.Conv2d(cin, cout, k, stride, pad).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(_mk(conv.weight.shape, 1, (cin * k * k) ** -0.5))
+        conv.bias.copy_(_mk(conv.bias.shape, 2, 0.1))
+    x = _mk((3, hw[0], hw[1], cin), 3)
+    y = co.run(co.pack_conv2d(conv), x, prec=prec)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), conv.weight.double(), conv.bias.double(), stride, pad)
+    mx, l2 = _err(y.permute(0, 3, 1, 2), ref)
+    report(f"conv_{cin}_{cout}_k{k}s{stride}_p{prec}", dict(max=mx, l2=l2))
+    assert (mx < 2e-5) if prec == 3 else (mx < 1e-2 and l2 < 4e-3), (mx, l2)
+
+
+def test_conv_fused_relu_residuals_and_acts():
+    from iggt_official_amd.heads import convops as co
+
+    conv = nn.Conv2d(256, 256, 3, 1, 1).cuda()
+    x, r1, r2 = _mk((2, 20, 28, 256), 4), _mk((2, 20, 28, 256), 5), _mk((2, 20, 28, 256), 6)
+    pc = co.pack_conv2d(conv)
+    xd = x.permute(0, 3, 1, 2).double()
+    base = F.conv2d(F.relu(xd), conv.weight.double(), conv.bias.double(), 1, 1)
+    y = co.run(pc, x, relu_in=True, res=r1, relu_res=True, res2=r2)
+    ref = base + F.relu(r1.permute(0, 3, 1, 2).double()) + r2.permute(0, 3, 1, 2).double()
+    assert _err(y.permute(0, 3, 1, 2), ref)[0] < 2e-5
+    for act, fn in [(1, F.relu), (2, lambda t: F.leaky_relu(t, 0.01)), (3, F.gelu)]:
+        y = co.run(pc, x, relu_in=True, act=act)
+        assert _err(y.permute(0, 3, 1, 2), fn(base))[0] < 2e-5, act
+
+
+def test_conv_bn_fold_and_channel_padding():
+    from iggt_official_amd.heads import convops as co
+
+    conv, bn = nn.Conv2d(128, 42, 3, 1, 1, bias=False).cuda(), nn.BatchNorm2d(42).cuda().eval()
+    with torch.no_grad():
+        bn.running_mean.copy_(_mk((42,), 7, 0.3)); bn.running_var.copy_(_mk((42,), 8).abs() + 0.5)
+        bn.weight.copy_(_mk((42,), 9) * 0.1 + 1); bn.bias.copy_(_mk((42,), 10, 0.1))
+    x = _mk((2, 16, 24, 128), 11)
+    y = co.run(co.pack_conv2d(conv, bn), x, ldy=64)
+    ref = bn(conv(x.permute(0, 3, 1, 2))).double()
+    assert y.shape[-1] == 64 and torch.all(y[..., 42:] == 0)
+    assert _err(y[..., :42].permute(0, 3, 1, 2), ref)[0] < 5e-5
+    conv2 = nn.Conv2d(42, 128, 3, 1, 1).cuda()
+    y2 = co.run(co.pack_conv2d(conv2, cin_pad=64), y)
+    ref2 = conv2(ref.float()).double()
+    assert _err(y2.permute(0, 3, 1, 2), ref2)[0] < 5e-5
+
+
+@pytest.mark.parametrize("s", [2, 4])
+def test_conv_transpose_kernel_eq_stride(s):
+    from iggt_official_amd.heads import convops as co
+
+    ct = nn.ConvTranspose2d(256, 256, s, s, 0).cuda()
+    x = _mk((2, 9, 13, 256), 12)
+    y = co.run(co.pack_convT_kernel_eq_stride(ct), x)
+    ref = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), ct.weight.double(), ct.bias.double(), s, 0)
+    assert y.shape == (2, 9 * s, 13 * s, 256)
+    assert _err(y.permute(0, 3, 1, 2), ref)[0] < 2e-5
+
+
+def test_conv_transpose_k4s2p1():
+    from iggt_official_amd.heads import convops as co
+
+    ct = nn.ConvTranspose2d(256, 256, 4, 2, 1).cuda()
+    x = _mk((2, 7, 10, 256), 13)
+    y = co.run_convT_k4s2p1(co.pack_convT_k4s2p1(ct), x)
+    ref = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), ct.weight.double(), ct.bias.double(), 2, 1)
+    assert y.shape == (2, 14, 20, 256)
+    assert _err(y.permute(0, 3, 1, 2), ref)[0] < 2e-5
+
+
+@pytest.mark.parametrize("hi,ho", [((19, 19), (37, 37)), ((37, 24), (74, 48)), ((296, 296), (518, 518)),
+                                   ((8, 12), (8, 12))])
+def test_bilinear_align_corners(hi, ho):
+    from iggt_official_amd.heads import convops as co
+
+    x = _mk((2, hi[0], hi[1], 128), 14)
+    y = co.resize(x, ho)
+    ref = F.interpolate(x.permute(0, 3, 1, 2), size=ho, mode="bilinear", align_corners=True)
+    assert _err(y.permute(0, 3, 1, 2), ref)[0] < 1e-5
+    xr, yr = _mk((ho[1], 64), 15), _mk((ho[0], 64), 16)
+    y2 = co.resize(x, ho, xr, yr)
+    add = torch.cat([xr.t()[None, :, None, :].expand(1, 64, ho[0], ho[1]),
+                     yr.t()[None, :, :, None].expand(1, 64, ho[0], ho[1])], 1)
+    assert _err(y2.permute(0, 3, 1, 2), ref + add)[0] < 1e-5
