@@ -35,6 +35,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+# HBM-side bytes per global-attention launch at 32 views x 518^2 on one GPU, from rocprofv3 PMC passes
+# (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE): profiles/r01_attn_hbm_pmc.txt.  Not measurable live.
+PMC_TRAFFIC_BYTES = {(32, 518, 1): 1.17e9}
 
 
 def usable_cores():
@@ -176,9 +179,12 @@ def main():
             "config": {"workload": f"{S} views @ {H}x{H}, IGGT forward (DINOv2 + 24x(frame,global) + camera/depth/"
                                    "point heads), random-init weights, views sharded " + f"{S // world}/GPU",
                        "views": S, "image_size": H, "tokens_per_view": P, "parallelism": f"view-shard x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "flash_attn_d64_kernel (global attention)",
+            "roofline": {"bound": "mfma", "kernel": "flash_attn_d64_v2_kernel<2> (global attention)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+                         "traffic": PMC_TRAFFIC_BYTES.get((S, H, world)),
+                         "traffic_note": "bytes/launch from rocprofv3 PMC passes, profiles/r01_attn_hbm_pmc.txt",
+                         "algorithmic_bytes_per_launch": 4.0 * Nk * C * 2,
                          "launches_timed": len(recs), "ms_per_launch": ms,
                          "flops_per_launch": flops},
         }

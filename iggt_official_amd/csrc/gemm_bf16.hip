@@ -17,33 +17,16 @@
 // (split issue/write), double-buffered LDS (64 KiB -> 2 workgroups/CU), XOR-swizzled rows
 // (common.h swz_off) so the ds_read_b128 operand reads are bank-conflict free.
 // Grid: 1-D over (m-tile, n-tile), n fastest, XCD-chunked so one XCD's L2 keeps the A row-panel.
+#include <stdlib.h>
+
 #include "common.h"
+#include "gemm_common.h"
 #include "../../include/iggt_hip.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per buffer
-
-struct GemmParams {
-    const bf16_t* A;
-    const bf16_t* W;
-    int M, N, K;
-    long lda, ldw;
-    int tiles_n;
-    // epilogue
-    const float* bias;       // [N] or null
-    const float* gamma;      // [N] or null
-    const float* add_table;  // [rows_in][N] fp32 or null, indexed by (m % rows_in)
-    float* out_f32;          // exactly one of out_f32 / out_bf16
-    bf16_t* out_bf16;
-    long ldo;
-    int accumulate;  // out_f32 += value
-    int act;         // 0 none, 1 exact GELU, 2 ReLU
-    int rows_in, rows_out, row_off;  // output row remap (rows_in == 0: identity)
-};
-
-IGGT_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -128,37 +111,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-        const float gamma = p.gamma ? p.gamma[n] : 1.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
-                if (m >= p.M) continue;
-                float val = acc[i][j][r] + bias;
-                if (p.act == 1) val = gelu_erf(val);
-                else if (p.act == 2) val = fmaxf(val, 0.f);
-                val *= gamma;
-                long orow = m;
-                if (p.rows_in > 0) {
-                    const int g = m / p.rows_in, w = m - g * p.rows_in;
-                    orow = (long)g * p.rows_out + p.row_off + w;
-                    if (p.add_table) val += p.add_table[(long)w * p.N + n];
-                }
-                if (p.out_f32) {
-                    float* dst = p.out_f32 + orow * p.ldo + n;
-                    *dst = p.accumulate ? (*dst + val) : val;
-                } else {
-                    p.out_bf16[orow * p.ldo + n] = (bf16_t)val;
-                }
-            }
-        }
+        for (int i = 0; i < 2; ++i) gemm_epilogue_tile<0>(p, acc[i][j], m0 + wm * 64 + i * 32, n, lane);
     }
 }
 
 }  // namespace
+
+static int force_small_tile() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("IGGT_GEMM_TILE128");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v;
+}
 
 extern "C" int iggt_gemm_bf16(const void* A, long lda, const void* W, long ldw, int M, int N, int K,
                               const float* bias, const float* gamma, const float* add_table,
@@ -180,6 +147,15 @@ extern "C" int iggt_gemm_bf16(const void* A, long lda, const void* W, long ldw, 
     p.ldo = ldo;
     p.accumulate = accumulate; p.act = act;
     p.rows_in = rows_in; p.rows_out = rows_out; p.row_off = row_off;
+    // large problems: 256x256 LDS-DMA kernel (gemm_bf16_t256.hip); small / ragged-N ones: this 128x128 kernel
+    if (M >= 1024 && (N % 256) == 0 && force_small_tile() == 0) {
+        const int rc = iggt_launch_gemm_t256(p, (hipStream_t)stream);
+        if (rc == 0) {
+            IGGT_CHECK_LAUNCH();
+            return 0;
+        }
+        if (rc != -100) return rc;
+    }
     const int tiles_m = (M + BM - 1) / BM;
     const int lds = 2 * 2 * TILE_BYTES;  // 64 KiB
     static bool attr_set = false;

@@ -1,0 +1,70 @@
+// Shared parameter block + fused epilogue of the bf16 MFMA GEMM kernels (gemm_bf16.hip, gemm_bf16_t256.hip).
+#pragma once
+#include "common.h"
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* W;
+    int M, N, K;
+    long lda, ldw;
+    int tiles_n;
+    // epilogue
+    const float* bias;       // [N] or null
+    const float* gamma;      // [N] or null
+    const float* add_table;  // [rows_in][N] fp32 or null, indexed by (m % rows_in)
+    float* out_f32;          // exactly one of out_f32 / out_bf16
+    bf16_t* out_bf16;
+    long ldo;
+    int accumulate;  // out_f32 += value
+    int act;         // 0 none, 1 exact GELU, 2 ReLU
+    int rows_in, rows_out, row_off;  // output row remap (rows_in == 0: identity)
+};
+
+IGGT_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Epilogue of one 32x32 accumulator fragment whose top-left element is (m_base, n - (lane & 31)):
+//   val = act(acc + bias[n]) * gamma[n] (+ add_table[m % rows_in][n]);  out[row(m)][n] (= | +=) val
+// MODE 0: every feature (runtime flags).  Specialised modes keep the inlined code (and with it the register
+// allocation of the big-tile kernel) small:  1 = bf16 out, bias + act;  2 = fp32 accumulate, bias + gamma;
+// 3 = fp32 store, bias (+ row remap / additive table).
+template <int MODE>
+IGGT_DEVINL void gemm_epilogue_tile(const GemmParams& p, const f32x16& acc, int m_base, int n, int lane) {
+    if (n >= p.N) return;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    const float gamma = (MODE == 0 || MODE == 2) ? (p.gamma ? p.gamma[n] : 1.f) : 1.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m_base + mfma32_row(r, lane);
+        if (m >= p.M) continue;
+        float val = acc[r] + bias;
+        if (MODE == 0 || MODE == 1) {
+            if (p.act == 1) val = gelu_erf(val);
+            else if (p.act == 2) val = fmaxf(val, 0.f);
+        }
+        if (MODE == 0 || MODE == 2) val *= gamma;
+        long orow = m;
+        if (MODE == 0 || MODE == 3) {
+            if (p.rows_in > 0) {
+                const int g = m / p.rows_in, w = m - g * p.rows_in;
+                orow = (long)g * p.rows_out + p.row_off + w;
+                if (p.add_table) val += p.add_table[(long)w * p.N + n];
+            }
+        }
+        if (MODE == 1) {
+            p.out_bf16[orow * p.ldo + n] = (bf16_t)val;
+        } else if (MODE == 2) {
+            float* dst = p.out_f32 + orow * p.ldo + n;
+            *dst = *dst + val;
+        } else if (MODE == 3) {
+            p.out_f32[orow * p.ldo + n] = val;
+        } else if (p.out_f32) {
+            float* dst = p.out_f32 + orow * p.ldo + n;
+            *dst = p.accumulate ? (*dst + val) : val;
+        } else {
+            p.out_bf16[orow * p.ldo + n] = (bf16_t)val;
+        }
+    }
+}
+
+// returns -100 when the parameter combination has no specialised big-tile kernel (caller falls back)
+int iggt_launch_gemm_t256(const GemmParams& p, hipStream_t stream);

@@ -256,3 +256,41 @@ def test_im2row_and_special_tokens(C):
     assert torch.all(dst[:, 5:] == 0)
     C.write_special_tokens(dst, a, b, 3, 5, 0, False)
     assert torch.equal(dst[0, :5], b)
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(5000, 4096, 1024, "gelu"), (4122, 1024, 4096, "acc"), (2738, 1024, 640, "remap"),
+                                        (43968, 3072, 1024, "plain"), (1024, 256, 2048, "plain")])
+def test_gemm_large_tile_path(C, M, N, K, mode):
+    """Shapes routed to the 256x256 LDS-DMA kernel (M >= 1024, N % 256 == 0): tails, epilogues, remap."""
+    a = _rand((M, K), 70, dtype=torch.bfloat16)
+    w = _rand((N, K), 71, K ** -0.5, dtype=torch.bfloat16)
+    bias, gamma = _rand((N,), 72, 0.1), _rand((N,), 73)
+    base = (a.double() @ w.double().t() + bias.double()) if M < 20000 else None
+    if mode == "gelu":
+        out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        C.gemm_bf16(a, w, out, bias=bias, act=1)
+        mx, l2 = _relerr(out, torch.nn.functional.gelu(base))
+        assert mx < 6e-3 and l2 < 3e-3
+    elif mode == "acc":
+        x = _rand((M, N), 74)
+        ref = x.double() + gamma.double() * base
+        C.gemm_bf16(a, w, x, bias=bias, gamma=gamma, accumulate=True)
+        assert _relerr(x, ref)[0] < 2e-5
+    elif mode == "remap":
+        g2 = 1369
+        S = M // g2
+        table = _rand((g2, N), 75)
+        out = torch.full((S * (g2 + 5), N), -7.0, device="cuda")
+        C.gemm_bf16(a, w, out, bias=bias, add_table=table, rows_in=g2, rows_out=g2 + 5, row_off=5)
+        o = out.view(S, g2 + 5, N)
+        assert torch.all(o[:, :5] == -7.0)
+        assert _relerr(o[:, 5:], base.view(S, g2, N) + table.double())[0] < 2e-5
+    else:
+        out = torch.full((M, N), float("nan"), device="cuda")
+        C.gemm_bf16(a, w, out, bias=bias)
+        if base is None:   # too big for an fp64 matmul of the whole thing: check a row sample
+            rows = torch.arange(0, M, 97, device="cuda")
+            base_s = a[rows].double() @ w.double().t() + bias.double()
+            assert not torch.isnan(out).any() and _relerr(out[rows], base_s)[0] < 2e-5
+        else:
+            assert _relerr(out, base)[0] < 2e-5
