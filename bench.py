@@ -179,7 +179,7 @@ def main():
             "config": {"workload": f"{S} views @ {H}x{H}, IGGT forward (DINOv2 + 24x(frame,global) + camera/depth/"
                                    "point heads), random-init weights, views sharded " + f"{S // world}/GPU",
                        "views": S, "image_size": H, "tokens_per_view": P, "parallelism": f"view-shard x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "flash_attn_d64_v2_kernel<2> (global attention)",
+            "roofline": {"bound": "mfma", "kernel": "flash_attn_d64_v3_kernel<2,2> (global attention)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": PMC_TRAFFIC_BYTES.get((S, H, world)),

@@ -472,10 +472,11 @@ extern "C" int iggt_flash_attn_bf16_d64(const void* q, const void* k, const void
     p.scale_log2 = scale * 1.4426950408889634f;
     if (q_rows_per_wg == 0) {
         // pick the tile that wastes the fewest padded query rows; ties -> larger tile (more K/V reuse).
-        // Default kernel = v2 (staggered query blocks + deferred max, attention_v2.hip): measured
-        // 860 vs 805 TF/s on the 32-view global attention (profiles/r01_attn_variants.txt).
+        // Default kernel = v3 (attention_v3.hip: staggered query blocks, deferred max, LDS-DMA staging,
+        // 128-key macro tiles for the 256-row tile): 32-view global attention 805 (v1) -> 860 (v2) -> 930-940 TF/s
+        // (profiles/r01_attn_variants.txt).
         const int pad256 = ((Nq + 255) / 256) * 256, pad128 = ((Nq + 127) / 128) * 128;
-        q_rows_per_wg = (pad256 <= pad128 + pad128 / 32) ? 1256 : 1128;
+        q_rows_per_wg = (pad256 <= pad128 + pad128 / 32) ? 6256 : 5128;
     }
     if (q_rows_per_wg == 256) {
         p.qtiles = (Nq + 255) / 256;
@@ -485,6 +486,8 @@ extern "C" int iggt_flash_attn_bf16_d64(const void* q, const void* k, const void
         hipLaunchKernelGGL(flash_attn_d64_kernel<1>, dim3(B * H * p.qtiles), dim3(256), 0, (hipStream_t)stream, p);
     } else if (q_rows_per_wg == 1128 || q_rows_per_wg == 1256 || q_rows_per_wg == 2256 || q_rows_per_wg == 3256) {
         iggt_launch_flash_attn_v2(p, q_rows_per_wg - 1000, (hipStream_t)stream);
+    } else if (q_rows_per_wg == 5128 || q_rows_per_wg == 5256 || q_rows_per_wg == 6128 || q_rows_per_wg == 6256 || q_rows_per_wg == 7256) {
+        iggt_launch_flash_attn_v3(p, q_rows_per_wg % 1000, q_rows_per_wg / 1000 - 4, (hipStream_t)stream);
     } else if (q_rows_per_wg == 512) {
         p.qtiles = (Nq + 511) / 512;
         hipLaunchKernelGGL(flash_attn_d64_pp_kernel<2>, dim3(B * H * p.qtiles), dim3(512), 0, (hipStream_t)stream, p);

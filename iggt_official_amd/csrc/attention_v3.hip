@@ -1,0 +1,263 @@
+// Flash attention d=64, variant 3: variant 2 (staggered query blocks + deferred max) with LDS-DMA staging
+// (global_load_lds, swizzle applied to the source address) and KVM x 64-key macro tiles per barrier.
+//
+// Same data layout, LDS images, swapped-QK^T / in-register-P scheme as attention.hip (see there).
+// PMC on the v1 kernel at 32 views (profiles/r01_attn_pmc.txt): matrix pipe busy 32-38 %, VALU issue
+// busy ~60 %, and the two are almost serialised because a wave's MFMAs (QK^T, then PV) and its
+// softmax VALU work sit in separate dependent phases.  v2 staggers the two 32-row query blocks of a
+// wave so that every MFMA group has independent VALU work of the *other* block next to it in the
+// same basic block:
+//
+//      [QK^T(q0)] [max(q0)] | [QK^T(q1)  ||  exp/sum/pack(q0)] [max(q1)] | [PV(q0) || exp/sum/pack(q1)] | [PV(q1)]
+//
+// and removes the per-tile O rescale: the running max m is only advanced (and O, l rescaled) when
+// some row's tile maximum exceeds m by more than 2^THR (wave-uniform vote, rare after the first
+// tiles); P = exp2(s*c - m) is then bounded by 2^THR, harmless in bf16/fp32 (guide T13).
+// K and V fragments are re-read from LDS for the second block (LDS pipe is < 20 % busy).
+#include "attention_common.h"
+#include "../../include/iggt_hip.h"
+
+using namespace iggt_attn;
+
+namespace {
+
+constexpr float DEFER_THR = 4.0f;  // log2 units: P <= 16
+
+template <int QB, int KVM, int PRIO = 0>
+__global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * KVM * BUF_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fhalf = lane >> 5;
+
+    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = work % p.qtiles;
+    const int bh = work / p.qtiles;
+    const int h = bh % p.H, b = bh / p.H;
+    const bf16_t* qb_ptr = p.q + (long)b * p.q_bs + h * 64;
+    const bf16_t* kb_ptr = p.k + (long)b * p.k_bs + h * 64;
+    const bf16_t* vb_ptr = p.v + (long)b * p.v_bs + h * 64;
+    bf16_t* ob_ptr = p.o + (long)b * p.o_bs + h * 64;
+
+    const int q_base = qt * (128 * QB) + wave * (32 * QB);
+    bf16x8 qf[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        int qr = q_base + qb * 32 + frow;
+        qr = qr < p.Nq ? qr : p.Nq - 1;
+        const bf16_t* src = qb_ptr + (long)qr * p.q_rs + 8 * fhalf;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) qf[qb][kc] = *reinterpret_cast<const bf16x8*>(src + 16 * kc);
+    }
+
+    // ---- LDS-DMA staging: a 64-key K (or V) tile is 8 chunks of 1 KiB (8 rows x 128 B); wave w moves chunks
+    //      2w, 2w+1 of K and of V.  Lane l fills row 8j + l/8, 16-B slot l%8; the row-image swizzles are applied
+    //      to the SOURCE piece (K: slot ^ ((row>>1)&7); V: 32-B chunk ^ (row&2)).  Rows past Nk are clamped to the
+    //      last valid row (finite data; their scores are masked to -inf, so they contribute exactly 0).
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int c_row = lane >> 3, c_pos = lane & 7;
+    auto dma = [&](int mt, int buf) {   // macro tile mt -> buffer buf
+        char* base = smem + buf * (KVM * BUF_BYTES);
+#pragma unroll
+        for (int sub = 0; sub < KVM; ++sub) {
+            char* sK = base + sub * BUF_BYTES;
+            char* sV = sK + K_BYTES;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = (2 * wave + i) * 8 + c_row;  // row within the 64-key tile
+                int kv = (mt * KVM + sub) * KV_TILE + r;
+                kv = kv < p.Nk ? kv : p.Nk - 1;
+                const int kpiece = c_pos ^ ((r >> 1) & 7);
+                const int vpiece = (((c_pos >> 1) ^ (r & 2)) << 1) | (c_pos & 1);
+                const int chunk = (2 * wave + i) * 1024;
+                __builtin_amdgcn_global_load_lds((gptr_t*)(kb_ptr + (long)kv * p.k_rs + kpiece * 8),
+                                                 (lptr_t*)(sK + chunk), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t*)(vb_ptr + (long)kv * p.v_rs + vpiece * 8),
+                                                 (lptr_t*)(sV + chunk), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 o[QB][2];
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = -1e30f;
+        l_run[qb] = 0.f;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][dh][r] = 0.f;
+    }
+    const int tr_i = lane & 15, tr_g = (lane >> 4) & 1;
+    const float c = p.scale_log2;
+    const int NT = (p.Nk + KV_TILE - 1) / KV_TILE;
+
+    // ---- building blocks ---------------------------------------------------------------------
+    auto qk = [&](const char* sK, int qb, f32x16 (&s)[2]) {
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kvh = 0; kvh < 2; ++kvh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kvh][r] = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const bf16x8 kf =
+                    *reinterpret_cast<const bf16x8*>(sK + swz_off(kvh * 32 + frow, 2 * kc + fhalf));
+                s[kvh] = mfma32(kf, qf[qb][kc], s[kvh]);
+            }
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+    auto mask_tail = [&](int t, f32x16 (&s)[2]) {
+        const int kv0 = t * KV_TILE + 4 * fhalf;
+#pragma unroll
+        for (int kvh = 0; kvh < 2; ++kvh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kv0 + kvh * 32 + (r & 3) + 8 * (r >> 2);
+                if (kv >= p.Nk) s[kvh][r] = -INFINITY;
+            }
+    };
+    // row max of the tile; advance m (rescaling O and l) only if some row needs it
+    auto update_max = [&](int qb, const f32x16 (&s)[2]) {
+        float mx = s[0][0];
+#pragma unroll
+        for (int kvh = 0; kvh < 2; ++kvh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kvh][r]);
+        {   // exchange with lane^32 on the VALU (v_permlane32_swap) instead of an LDS-pipe ds_bpermute
+            const uint32_t bits = __builtin_bit_cast(uint32_t, mx);
+            const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1])) * c;
+        }
+        if (__any(mx > m_run[qb] + DEFER_THR)) {
+            const float m_new = fmaxf(m_run[qb], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+            m_run[qb] = m_new;
+            l_run[qb] *= alpha;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][dh][r] *= alpha;
+        }
+    };
+    auto exp_pack = [&](int qb, f32x16 (&s)[2], bf16x8 (&pf)[2][2]) {
+        const float m = m_run[qb];
+        float ls0 = 0.f, ls1 = 0.f, ls2 = 0.f, ls3 = 0.f;
+#pragma unroll
+        for (int kvh = 0; kvh < 2; ++kvh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a = __builtin_fmaf(s[kvh][r], c, -m);
+                s[kvh][r] = __builtin_amdgcn_exp2f(a);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                ls0 += s[kvh][r];
+                ls1 += s[kvh][r + 1];
+                ls2 += s[kvh][r + 2];
+                ls3 += s[kvh][r + 3];
+            }
+            pf[kvh][0] = pack8(s[kvh], 0);
+            pf[kvh][1] = pack8(s[kvh], 8);
+        }
+        l_run[qb] += (ls0 + ls1) + (ls2 + ls3);
+    };
+    auto pv = [&](const char* sV, int qb, const bf16x8 (&pf)[2][2]) {
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kvh = 0; kvh < 2; ++kvh)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh) {
+                    const int kvb = kvh * 32 + 16 * cc + 4 * fhalf;
+                    const int row0 = kvb + (tr_i >> 2);
+                    const int chunk = dh * 2 + tr_g;
+                    typedef __attribute__((address_space(3))) short4v lds_s4;
+                    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (lds_s4*)(sV + v_lds_off(row0, chunk) + 8 * (tr_i & 3)));
+                    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (lds_s4*)(sV + v_lds_off(row0 + 8, chunk) + 8 * (tr_i & 3)));
+                    typedef short short8v __attribute__((ext_vector_type(8)));
+                    const short8v v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[qb][dh] = mfma32(__builtin_bit_cast(bf16x8, v8), pf[kvh][cc], o[qb][dh]);
+                }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+
+    const int NMT = (NT + KVM - 1) / KVM;
+    dma(0, 0);
+    __syncthreads();  // vmcnt(0) + barrier: macro tile 0 resident
+    for (int mt = 0; mt < NMT; ++mt) {
+        if (mt + 1 < NMT) dma(mt + 1, (mt + 1) & 1);
+#pragma unroll
+        for (int sub = 0; sub < KVM; ++sub) {
+            const int t = mt * KVM + sub;
+            if (t < NT) {
+                const char* sK = smem + (mt & 1) * (KVM * BUF_BYTES) + sub * BUF_BYTES;
+                const char* sV = sK + K_BYTES;
+                const bool tail = (t + 1) * KV_TILE > p.Nk;
+                f32x16 s0[2], s1[2];
+                bf16x8 pf0[2][2], pf1[2][2];
+                qk(sK, 0, s0);
+                if (tail) mask_tail(t, s0);
+                update_max(0, s0);
+                if constexpr (QB == 2) {
+                    qk(sK, 1, s1);
+                    exp_pack(0, s0, pf0);
+                    if (tail) mask_tail(t, s1);
+                    update_max(1, s1);
+                    pv(sV, 0, pf0);
+                    exp_pack(1, s1, pf1);
+                    pv(sV, 1, pf1);
+                } else {
+                    exp_pack(0, s0, pf0);
+                    pv(sV, 0, pf0);
+                }
+            }
+        }
+        __syncthreads();  // everyone done with buffer mt&1; DMA of macro tile mt+1 landed
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qr = q_base + qb * 32 + frow;
+        const float l = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.0f / l;
+        if (qr < p.Nq) {
+            bf16_t* dst = ob_ptr + (long)qr * p.o_rs + 4 * fhalf;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 w;
+                    w[0] = pack_bf16x2(o[qb][dh][4 * g + 0] * inv, o[qb][dh][4 * g + 1] * inv);
+                    w[1] = pack_bf16x2(o[qb][dh][4 * g + 2] * inv, o[qb][dh][4 * g + 3] * inv);
+                    *reinterpret_cast<u32x2*>(dst + dh * 32 + 8 * g) = w;
+                }
+        }
+    }
+}
+
+}  // namespace
+
+// Launched from iggt_flash_attn_bf16_d64 (attention.hip): code = 256 | 128 (q rows per WG) + 1000 * KVM.
+int iggt_launch_flash_attn_v3(const AttnParams& p_in, int q_rows, int kvm, hipStream_t stream) {
+    AttnParams p = p_in;
+    if (q_rows == 256) {
+        p.qtiles = (p.Nq + 255) / 256;
+        const dim3 grid(p.B * p.H * p.qtiles), block(256);
+        if (kvm == 3) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2, 1>), grid, block, 0, stream, p);
+        else if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 1>), grid, block, 0, stream, p);
+    } else {
+        p.qtiles = (p.Nq + 127) / 128;
+        const dim3 grid(p.B * p.H * p.qtiles), block(256);
+        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 2>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 1>), grid, block, 0, stream, p);
+    }
+    return 0;
+}
