@@ -1,28 +1,35 @@
-// 256x256x64 bf16 MFMA GEMM with LDS-DMA staging (global_load_lds) -- the large-M path of iggt_gemm_bf16.
+// 256x256 bf16 MFMA GEMM with a 4-stage LDS-DMA pipeline -- the large-M path of iggt_gemm_bf16.
 //
-// Why a second GEMM kernel: PMC/arithmetic on the 128^2 register-staged kernel (gemm_bf16.hip) shows the
-// LDS pipe, not the matrix pipe, is the limiter -- per K-step a 128^2 tile writes 32 KB through
-// ds_write_b128 (~79 B/clk/CU) and reads 64 KB for only 64 MFMAs.  This kernel
-//   * quadruples the tile (256x256, 8 waves as 2(M) x 4(N), 128x64 per wave = 32 MFMA 32x32x16 per K-step
-//     per wave): LDS bytes moved per MFMA drop from 1.5 KB to 0.625 KB;
-//   * stages operands with global_load_lds_dwordx4 (16 B/lane, no VGPR round trip, no ds_write);
-//     the LDS destination of that instruction is wave-uniform base + lane*16, so the XOR swizzle of the
-//     row image (common.h swz_off) is applied to the per-lane *source* address instead (guide rule 21):
-//     lane l of 1-KiB chunk j fills row 8j + l/8, slot l%8 with global piece (l%8) ^ key(row);
-//   * double-buffers the 64-KiB stage (128 KiB LDS, one workgroup per CU, 2 waves per SIMD); the next
-//     stage's DMA is issued before the MFMA phase and drained by the single barrier per K-step.
-// Same epilogue contract as gemm_bf16.hip.
+// Why a second GEMM kernel: arithmetic on the 128^2 register-staged kernel (gemm_bf16.hip) shows the LDS and
+// the per-CU vector-memory path, not the matrix pipe, are the limiters -- per K-step a 128^2 tile writes 32 KB
+// through ds_write_b128 (~79 B/clk/CU) and pulls only 64 FLOP per byte from L2.  This kernel
+//   * quadruples the tile (256x256, 8 waves as 2(M) x 4(N), 128x64 per wave): 128 FLOP per staged byte, LDS bytes
+//     moved per MFMA drop from 1.5 KB to 0.625 KB;
+//   * stages operands with global_load_lds_dwordx4 (16 B/lane, no VGPR round trip, no ds_write).  The LDS
+//     destination of that instruction is wave-uniform base + lane*16, so the XOR swizzle of the 64-byte row image
+//     is applied to the per-lane *source* address instead (guide rule 21): lane l of 1-KiB chunk j fills row
+//     16j + l/4, 16-B slot l%4 with source piece (l%4) ^ ((row >> 2) & 3) -- conflict-free ds_read_b128;
+//   * runs a 4-deep ring of 32-wide K stages (4 x 32 KiB = 128 KiB LDS, one workgroup per CU, 2 waves/SIMD) with
+//     three stages of DMA in flight: counted `s_waitcnt vmcnt(N)` + raw `s_barrier` (a __syncthreads() would
+//     drain the DMA queue every step -- guide section 5 "Pipelining across barriers").  One barrier per stage:
+//         wait(stage kt landed) ; barrier ; issue DMA(stage kt+3 -> buffer of stage kt-1) ; 16 MFMA on stage kt
+// Same epilogue contract as gemm_bf16.hip (specialised per mode to keep register allocation clean).
 #include "common.h"
 #include "gemm_common.h"
 
 namespace {
 
-constexpr int TM = 256, TN = 256, TK = 64;
-constexpr int OP_BYTES = TM * TK * 2;       // 32 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * OP_BYTES;   // A + W
+constexpr int TM = 256, TN = 256, TK = 32, NSTAGE = 4;
+constexpr int OP_BYTES = TM * TK * 2;       // 16 KiB per operand per stage
+constexpr int STAGE_BYTES = 2 * OP_BYTES;   // A + W = 32 KiB
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int N>
+IGGT_DEVINL void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(const GemmParams p) {
@@ -34,13 +41,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(const GemmParams
     const int tm = v / p.tiles_n, tn = v - tm * p.tiles_n;
     const int m0 = tm * TM, n0 = tn * TN;
 
-    // ---- DMA map: wave w moves chunks j = 4w..4w+3 (8 rows each) of A and of W per stage -----------
-    const int c_row = lane >> 3, c_pos = lane & 7;
-    int a_off[4], w_off[4];  // element offsets (M*lda, N*ldw < 2^31 for every IGGT shape; checked by the launcher)
+    // ---- DMA map: an operand stage is 16 chunks of 1 KiB (16 rows x 64 B); wave w moves chunks 2w, 2w+1 -------
+    const int c_row = lane >> 2, c_pos = lane & 3;
+    int a_off[2], w_off[2];  // element offsets (< 2^31, checked by the launcher)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (4 * wave + i) * 8 + c_row;           // tile row 0..255
-        const int piece = c_pos ^ ((r >> 1) & 7);           // source piece that belongs at LDS slot c_pos
+    for (int i = 0; i < 2; ++i) {
+        const int r = (2 * wave + i) * 16 + c_row;          // tile row 0..255
+        const int piece = c_pos ^ ((r >> 2) & 3);           // source 16-B piece that belongs at LDS slot c_pos
         int ra = m0 + r;
         ra = ra < p.M ? ra : p.M - 1;
         int rw = n0 + r;
@@ -48,12 +55,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(const GemmParams
         a_off[i] = ra * (int)p.lda + piece * 8;
         w_off[i] = rw * (int)p.ldw + piece * 8;
     }
-    auto dma = [&](int kt, int buf) {
-        char* sA = smem + buf * STAGE_BYTES;
+    auto dma = [&](int kt) {
+        char* sA = smem + (kt & (NSTAGE - 1)) * STAGE_BYTES;
         char* sW = sA + OP_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int chunk = (4 * wave + i) * 1024;
+        for (int i = 0; i < 2; ++i) {
+            const int chunk = (2 * wave + i) * 1024;
             __builtin_amdgcn_global_load_lds((gptr_t*)(p.A + a_off[i] + kt * TK), (lptr_t*)(sA + chunk), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t*)(p.W + w_off[i] + kt * TK), (lptr_t*)(sW + chunk), 16, 0, 0);
         }
@@ -69,40 +76,72 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(const GemmParams
 
     const int frow = lane & 31, fhalf = lane >> 5;
     const int KT = p.K / TK;
-    // LDS operand offsets: row = (multiple of 32) + frow, so the swizzle key ((row >> 1) & 7) depends on the
-    // lane only: 4 lane-dependent offsets (one per 16-wide k chunk), everything else is wave-uniform.
-    int lane_off[4];
+    // LDS operand offsets: row = (multiple of 32) + frow -> swizzle key ((row >> 2) & 3) depends on the lane only
+    int lane_off[2];
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) lane_off[kc] = frow * 128 + ((((2 * kc + fhalf) ^ (frow >> 1)) & 7) << 4);
-    const int a_base = wm * 128 * 128, w_base = OP_BYTES + wn * 64 * 128;
-    dma(0, 0);
-    __syncthreads();  // drains the DMA (vmcnt(0)) and publishes stage 0
+    for (int kc = 0; kc < 2; ++kc) lane_off[kc] = frow * 64 + ((((2 * kc + fhalf) ^ (frow >> 2)) & 3) << 4);
+    const int a_base = wm * 128 * 64, w_base = OP_BYTES + wn * 64 * 64;
+
+    // prologue: three stages in flight (4 DMA instructions per wave per stage)
+    dma(0);
+    if (KT > 1) dma(1);
+    if (KT > 2) dma(2);
 #pragma unroll 1
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) dma(kt + 1, (kt + 1) & 1);
-        const char* st = smem + (kt & 1) * STAGE_BYTES;
+        // stage kt must have landed: allow the DMAs of the (up to two) younger stages to stay in flight
+        const int younger = (KT - 1 - kt) < 2 ? (KT - 1 - kt) : 2;
+        if (younger == 2) wait_vmcnt<8>();
+        else if (younger == 1) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // publishes stage kt to all waves; everyone is done reading stage kt-1
+        if (kt + 3 < KT) dma(kt + 3);   // refill the buffer stage kt-1 just vacated
+        const char* st = smem + (kt & (NSTAGE - 1)) * STAGE_BYTES;
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
+        for (int kc = 0; kc < 2; ++kc) {
             bf16x8 a[4], b[2];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                a[i] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 32 * 128 + lane_off[kc]);
+                a[i] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 32 * 64 + lane_off[kc]);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                b[j] = *reinterpret_cast<const bf16x8*>(st + w_base + j * 32 * 128 + lane_off[kc]);
+                b[j] = *reinterpret_cast<const bf16x8*>(st + w_base + j * 32 * 64 + lane_off[kc]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
         }
-        __syncthreads();  // all waves done reading stage kt; DMA of stage kt+1 landed (vmcnt(0) + barrier)
     }
 
+    // ---- epilogue through LDS: the MFMA C layout gives every lane ONE column, i.e. 2/4-byte stores at a row
+    //      stride -- 128 store instructions per lane, measured at >50 % of the tile time at K = 1024 (store-issue
+    //      bound).  Instead each half of the tile (128 rows x 256 fp32 = 128 KiB, the whole ring) is transposed
+    //      through LDS and leaves as fully coalesced 16-byte accesses: one wave instruction = one 1-KiB output row.
+    wait_vmcnt<0>();
+    __syncthreads();
+    float* stile = reinterpret_cast<float*>(smem);
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gemm_epilogue_tile<MODE>(p, acc[i][j], m0 + wm * 128 + i * 32, n, lane);
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stile[(i * 32 + mfma32_row(r, lane)) * TN + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) {
+            const int idx = pass * 512 + tid;
+            const int row = idx >> 6, c4 = idx & 63;
+            const int m = m0 + half * 128 + row;
+            if (m < p.M) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stile + row * TN + c4 * 4);
+                gemm_epilogue_row4<MODE>(p, v, m, n0 + c4 * 4);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -110,10 +149,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(const GemmParams
 
 int iggt_launch_gemm_t256(const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
-    if ((long)p.M * p.lda >= (1L << 31) || (long)p.N * p.ldw >= (1L << 31)) return -6;
+    if ((long)p.M * p.lda >= (1L << 31) || (long)p.N * p.ldw >= (1L << 31)) return -100;
+    if ((p.ldo % 4) != 0) return -100;  // 16-byte epilogue accesses
     p.tiles_n = (p.N + TN - 1) / TN;
     const int tiles_m = (p.M + TM - 1) / TM;
-    const int lds = 2 * STAGE_BYTES;  // 128 KiB
+    const int lds = NSTAGE * STAGE_BYTES;  // 128 KiB
     int mode;
     if (p.out_bf16 && !p.gamma && p.rows_in == 0) mode = 1;
     else if (p.out_f32 && p.accumulate && p.rows_in == 0 && p.act == 0) mode = 2;

@@ -66,5 +66,51 @@ IGGT_DEVINL void gemm_epilogue_tile(const GemmParams& p, const f32x16& acc, int 
     }
 }
 
+// Same epilogue on 4 consecutive columns n..n+3 of row m (vector loads/stores; N % 4 == 0, n + 3 < N).
+template <int MODE>
+IGGT_DEVINL void gemm_epilogue_row4(const GemmParams& p, f32x4 v, int m, int n) {
+    if (p.bias) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += b[e];
+    }
+    if (MODE == 1) {
+        if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        } else if (p.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        u32x2 o;
+        o[0] = pack_bf16x2(v[0], v[1]);
+        o[1] = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(p.out_bf16 + (long)m * p.ldo + n) = o;
+    } else if (MODE == 2) {
+        if (p.gamma) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= g[e];
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(p.out_f32 + (long)m * p.ldo + n);
+        const f32x4 old = *dst;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += old[e];
+        *dst = v;
+    } else {
+        long orow = m;
+        if (p.rows_in > 0) {
+            const int g = m / p.rows_in, w = m - g * p.rows_in;
+            orow = (long)g * p.rows_out + p.row_off + w;
+            if (p.add_table) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p.add_table + (long)w * p.N + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += t[e];
+            }
+        }
+        *reinterpret_cast<f32x4*>(p.out_f32 + orow * p.ldo + n) = v;
+    }
+}
+
 // returns -100 when the parameter combination has no specialised big-tile kernel (caller falls back)
 int iggt_launch_gemm_t256(const GemmParams& p, hipStream_t stream);
