@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     static_assert(BM == 128 && WAVES_M * WAVES_N == 4, "256-thread tile");
     constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64;
     constexpr int STAGE = PREC * 0 + (PREC == 3 ? 2 : 1) * (A_BYTES + W_BYTES);
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    constexpr int SMEM = (2 * STAGE > BM * BN * 4) ? 2 * STAGE : BM * BN * 4;  // stage ring, reused by the epilogue
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -200,12 +201,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         __syncthreads();
     }
 
-    // ---- epilogue ----------------------------------------------------------------------------
+    // ---- epilogue through LDS ------------------------------------------------------------------
+    // The MFMA C layout gives a lane one column: 4-byte accesses at a row stride, 16*WM*WN store (+ residual
+    // load) instructions per lane -- store-issue bound (same finding as gemm_bf16_t256.hip).  The tile is
+    // transposed through the (now idle) stage buffers and leaves as 16-byte accesses, a wave covering whole
+    // contiguous output rows; bias / activation / residuals are applied on float4s.
+    float* stile = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
-        if (n >= p.Cout) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stile[((wm * WM + i) * 32 + mfma32_row(r, lane)) * BN + (wn * WN + j) * 32 + (lane & 31)] = acc[i][j][r];
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+#pragma unroll 4
+    for (int idx = tid; idx < BM * C4; idx += 256) {
+        const int row = idx / C4, c4 = idx - row * C4;
+        const long m = m0 + row;
+        const int n = n0 + c4 * 4;
+        if (m >= p.M || n >= p.Cout) continue;
+        const int img = (int)(m / hw);
+        const int rem = (int)(m - (long)img * hw);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         int co = n, py = 0, px = 0;
         if (p.ps > 1) {
             const int phase = n / p.cout_phys;
@@ -213,28 +232,48 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             py = phase / p.ps;
             px = phase - py * p.ps;
         }
+        const long pix = ((long)img * p.Hout + oy * p.osy + p.ooy + py) * p.Wout + ox * p.osx + p.oox + px;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stile + row * BN + c4 * 4);
+        const bool full = (n + 3 < p.Cout);  // Cout % 4 != 0 only for the padded 42-channel bottleneck
+        if (p.bias) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
+            for (int e = 0; e < 4; ++e) v[e] += (full || n + e < p.Cout) ? p.bias[n + e] : 0.f;
+        }
+        if (p.act == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long m = m0 + (wm * WM + i) * 32 + mfma32_row(r, lane);
-                if (m >= p.M) continue;
-                const int img = (int)(m / hw);
-                const int rem = (int)(m - (long)img * hw);
-                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-                const long pix = ((long)img * p.Hout + oy * p.osy + p.ooy + py) * p.Wout + ox * p.osx + p.oox + px;
-                float val = acc[i][j][r] + bias;
-                if (p.act == 1) val = fmaxf(val, 0.f);
-                else if (p.act == 2) val = val > 0.f ? val : 0.01f * val;
-                else if (p.act == 3) val = 0.5f * val * (1.0f + erff(val * 0.70710678118654752440f));
-                if (p.res) {
-                    float rv = p.res[pix * p.ldr + co];
-                    if (p.relu_res) rv = fmaxf(rv, 0.f);
-                    val += rv;
-                    if (p.res2) val += p.res2[pix * p.ldr + co];
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+        } else if (p.act == 3) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        }
+        if (full) {
+            if (p.res) {
+                f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + co);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += p.relu_res ? fmaxf(rv[e], 0.f) : rv[e];
+                if (p.res2) {
+                    rv = *reinterpret_cast<const f32x4*>(p.res2 + pix * p.ldr + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
                 }
-                p.y[pix * p.ldy + co] = val;
             }
+            *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + co) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e >= p.Cout) break;
+                float val = v[e];
+                if (p.res) {
+                    const float rv = p.res[pix * p.ldr + co + e];
+                    val += p.relu_res ? fmaxf(rv, 0.f) : rv;
+                    if (p.res2) val += p.res2[pix * p.ldr + co + e];
+                }
+                p.y[pix * p.ldy + co + e] = val;
+            }
+        }
     }
 }
 
@@ -258,6 +297,7 @@ extern "C" int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, c
                                     void* stream) {
     if (Nimg <= 0 || Cin <= 0 || (Cin % BK) != 0 || Cout <= 0 || KH <= 0 || KW <= 0) return -1;
     if ((ldx % 4) != 0 || ldx < Cin) return -2;
+    if ((ldy % 4) != 0 || (res && (ldr % 4) != 0) || (cout_phys % 4) != 0 && ps > 1) return -2;
     if (prec != 1 && prec != 3) return -3;
     if (prec == 3 && w_lo == nullptr) return -3;
     if (res2 && !res) return -5;
