@@ -56,13 +56,22 @@ class ViewShard:
         """kv_local [T_l, 2C] (contiguous) -> [world*T_l, 2C], rank-major = view-major token order."""
         assert kv_local.is_contiguous()
         out = self._buf("kv_all", (self.world * kv_local.shape[0], kv_local.shape[1]), kv_local)
-        dist.all_gather_into_tensor(out, kv_local, group=self.group)
+        self._gather(out, kv_local)
         return out
+
+    def _gather(self, out, x):
+        """all_gather_into_tensor (RCCL: one direct all-gather); list-based fallback for backends that lack the
+        flat variant for device tensors (gloo, used by the single-GPU two-rank test)."""
+        try:
+            dist.all_gather_into_tensor(out, x, group=self.group)
+        except (RuntimeError, NotImplementedError):
+            parts = list(out.view(self.world, *x.shape).unbind(0))
+            dist.all_gather(parts, x, group=self.group)
 
     def all_gather_rows(self, x_local: torch.Tensor) -> torch.Tensor:
         """[n_l, ...] -> [world*n_l, ...] (camera tokens, small outputs)."""
         x_local = x_local.contiguous()
         out = torch.empty((self.world * x_local.shape[0],) + tuple(x_local.shape[1:]), dtype=x_local.dtype,
                           device=x_local.device)
-        dist.all_gather_into_tensor(out, x_local, group=self.group)
+        self._gather(out, x_local)
         return out
