@@ -484,9 +484,7 @@ extern "C" int iggt_flash_attn_bf16_d64(const void* q, const void* k, const void
     } else if (q_rows_per_wg == 128) {
         p.qtiles = (Nq + 127) / 128;
         hipLaunchKernelGGL(flash_attn_d64_kernel<1>, dim3(B * H * p.qtiles), dim3(256), 0, (hipStream_t)stream, p);
-    } else if (q_rows_per_wg == 1128 || q_rows_per_wg == 1256 || q_rows_per_wg == 2256 || q_rows_per_wg == 3256) {
-        iggt_launch_flash_attn_v2(p, q_rows_per_wg - 1000, (hipStream_t)stream);
-    } else if (q_rows_per_wg == 5128 || q_rows_per_wg == 5256 || q_rows_per_wg == 6128 || q_rows_per_wg == 6256 || q_rows_per_wg == 7256) {
+    } else if (q_rows_per_wg == 5128 || q_rows_per_wg == 5256 || q_rows_per_wg == 6128 || q_rows_per_wg == 6256) {
         iggt_launch_flash_attn_v3(p, q_rows_per_wg % 1000, q_rows_per_wg / 1000 - 4, (hipStream_t)stream);
     } else if (q_rows_per_wg == 512) {
         p.qtiles = (Nq + 511) / 512;

@@ -33,4 +33,3 @@ IGGT_DEVINL bf16x8 pack8(const f32x16& s, int base) {
 
 // experimental variants live in their own translation units
 int iggt_launch_flash_attn_v3(const iggt_attn::AttnParams& p, int q_rows, int kvm, hipStream_t stream);
-int iggt_launch_flash_attn_v2(const iggt_attn::AttnParams& p, int q_rows, hipStream_t stream);

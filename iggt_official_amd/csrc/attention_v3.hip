@@ -1,19 +1,22 @@
-// Flash attention d=64, variant 3: variant 2 (staggered query blocks + deferred max) with LDS-DMA staging
-// (global_load_lds, swizzle applied to the source address) and KVM x 64-key macro tiles per barrier.
+// Flash attention d=64, production kernel ("v3").
 //
-// Same data layout, LDS images, swapped-QK^T / in-register-P scheme as attention.hip (see there).
-// PMC on the v1 kernel at 32 views (profiles/r01_attn_pmc.txt): matrix pipe busy 32-38 %, VALU issue
-// busy ~60 %, and the two are almost serialised because a wave's MFMAs (QK^T, then PV) and its
-// softmax VALU work sit in separate dependent phases.  v2 staggers the two 32-row query blocks of a
-// wave so that every MFMA group has independent VALU work of the *other* block next to it in the
-// same basic block:
-//
-//      [QK^T(q0)] [max(q0)] | [QK^T(q1)  ||  exp/sum/pack(q0)] [max(q1)] | [PV(q0) || exp/sum/pack(q1)] | [PV(q1)]
-//
-// and removes the per-tile O rescale: the running max m is only advanced (and O, l rescaled) when
-// some row's tile maximum exceeds m by more than 2^THR (wave-uniform vote, rare after the first
-// tiles); P = exp2(s*c - m) is then bounded by 2^THR, harmless in bf16/fp32 (guide T13).
-// K and V fragments are re-read from LDS for the second block (LDS pipe is < 20 % busy).
+// Same data layout, LDS images, swapped-QK^T / in-register-P scheme as attention.hip (the v1 baseline, see there
+// for the MFMA/LDS layout derivations).  What changed, each step A/B-measured on the 32-view global attention
+// (N = 43 968, 16 heads; profiles/r01_attn_variants.txt, profiles/r01_attn_pmc.txt):
+//   v1  805 TF/s  PMC: matrix pipe ~35 % busy, VALU issue ~60 % busy, and the two nearly serialised because a
+//                 wave's MFMAs (QK^T, PV) and its softmax VALU work sit in separate dependent phases.
+//   +   staggered query blocks: the two 32-row blocks of a wave are offset so each MFMA group has independent
+//       VALU work of the other block in the same basic block
+//           [QK^T(q0)] [max(q0)] | [QK^T(q1) || exp/pack(q0)] [max(q1)] | [PV(q0) || exp/pack(q1)] | [PV(q1)]
+//       and deferred-max rescale: m only advances (O, l rescaled) when a row's tile max exceeds it by > 2^THR
+//       (wave vote, rare after the first tiles; guide T13); P <= 2^THR is harmless in bf16/fp32      -> 860 TF/s
+//   +   LDS-DMA staging (global_load_lds_dwordx4, swizzles applied to the source address, no staging VGPRs,
+//       no ds_write) and 128-key macro tiles (one barrier + one DMA drain per 128 keys)               -> 910 TF/s
+//   +   row-max exchange with lane^32 via v_permlane32_swap (VALU) instead of ds_bpermute (LDS pipe)  -> 940 TF/s
+// Tried and rejected (measured slower): 8-wave ping-pong specialisation (attention.hip, 725), s_setprio around
+// the MFMA groups (855), row sums on the matrix pipe with a ones fragment (880), side-stream tail balancing.
+// Ablation: the same kernel without any softmax VALU work reaches 1 210 TF/s -- the d = 64 softmax (64 exp +
+// ~140 other VALU ops per 32 MFMA) is what separates this kernel from the matrix-pipe limit.
 #include "attention_common.h"
 #include "../../include/iggt_hip.h"
 
@@ -23,7 +26,7 @@ namespace {
 
 constexpr float DEFER_THR = 4.0f;  // log2 units: P <= 16
 
-template <int QB, int KVM, int PRIO = 0>
+template <int QB, int KVM>
 __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KVM * BUF_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -96,7 +99,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
 
     // ---- building blocks ---------------------------------------------------------------------
     auto qk = [&](const char* sK, int qb, f32x16 (&s)[2]) {
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kvh = 0; kvh < 2; ++kvh) {
 #pragma unroll
@@ -108,7 +110,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                 s[kvh] = mfma32(kf, qf[qb][kc], s[kvh]);
             }
         }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
     auto mask_tail = [&](int t, f32x16 (&s)[2]) {
         const int kv0 = t * KV_TILE + 4 * fhalf;
@@ -166,7 +167,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         l_run[qb] += (ls0 + ls1) + (ls2 + ls3);
     };
     auto pv = [&](const char* sV, int qb, const bf16x8 (&pf)[2][2]) {
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kvh = 0; kvh < 2; ++kvh)
 #pragma unroll
@@ -185,7 +185,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                     const short8v v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     o[qb][dh] = mfma32(__builtin_bit_cast(bf16x8, v8), pf[kvh][cc], o[qb][dh]);
                 }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
     const int NMT = (NT + KVM - 1) / KVM;
@@ -250,8 +249,7 @@ int iggt_launch_flash_attn_v3(const AttnParams& p_in, int q_rows, int kvm, hipSt
     if (q_rows == 256) {
         p.qtiles = (p.Nq + 255) / 256;
         const dim3 grid(p.B * p.H * p.qtiles), block(256);
-        if (kvm == 3) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2, 1>), grid, block, 0, stream, p);
-        else if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2>), grid, block, 0, stream, p);
+        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 1>), grid, block, 0, stream, p);
     } else {
         p.qtiles = (p.Nq + 127) / 128;

@@ -118,8 +118,7 @@ def _attn_ref(q, k, v, scale):
                                             (1, 2, 300, 777, 128), (1, 2, 300, 777, 256), (3, 4, 21, 21, 0),
                                             (1, 16, 2748, 5496, 256), (1, 16, 4122, 4122, 512),
                                             (1, 2, 300, 777, 512), (2, 3, 1374, 1374, 512), (1, 1, 40, 64, 512),
-                                            (1, 2, 1000, 65, 512), (1, 16, 4122, 4122, 1256), (2, 3, 1374, 1374, 1128),
-                                            (1, 2, 300, 777, 1256), (1, 2, 300, 777, 1128), (1, 1, 40, 64, 1256),
+                                            (1, 2, 1000, 65, 512),
                                             (1, 16, 4122, 4122, 5256), (1, 16, 4122, 4122, 6256), (2, 3, 1374, 1374, 6128),
                                             (1, 2, 300, 777, 6256), (1, 2, 300, 777, 5128), (1, 1, 40, 64, 6256),
                                             (1, 2, 1000, 65, 6256), (1, 2, 500, 129, 6128)])
