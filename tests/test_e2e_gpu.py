@@ -4,9 +4,10 @@ modules on CPU fp32 (oracle/make_golden.py), same seeded weights and inputs.
 Tolerances.  north_star asks for 1e-3 relative on the outputs.  The trunk computes, like the
 reference's own GPU mode (demo.py:193-195 autocast bf16), with bf16 GEMM/attention operands; the
 reference's bf16 mode itself deviates from its fp32 CPU mode by 7e-3 on tokens and 1e-3..1e-2 on
-outputs.  Gates below are therefore set per
-quantity from the measured bf16 rounding budget and written next to each assert; every measured
-number is exported to gpurun_out/parity_report.json and discussed in DESIGN.md."""
+outputs.  Gate: relative l2 error < 1e-2 on the four consumed
+token layers and on every output (and max-abs error < 3e-2 of the output range); the per-kernel tests
+(test_kernels_gpu.py, test_conv_gpu.py) hold each HIP kernel to its own rounding budget.  Every measured number is
+exported to gpurun_out/parity_report.json and discussed in DESIGN.md section 2."""
 import pytest
 import torch
 
@@ -62,11 +63,12 @@ def test_forward_matches_reference(case):
     assert len(pred["pose_enc"]) == 4 and pred["pose_enc"][-1].shape == (1, S, 9)
     assert all(v.dtype == torch.float32 for v in pred.values() if torch.is_tensor(v))
     # gates: bf16-operand trunk vs fp32 CPU reference (see module docstring)
+    # measured on MI355X: tokens 6.2e-3..7.2e-3, outputs 6e-4..7.1e-3 (profiles/r01_parity_report.json)
     for li in (4, 11, 17, 23):
-        assert res[f"tokens_{li}"][1] < 2e-2, (li, res[f"tokens_{li}"])
+        assert res[f"tokens_{li}"][1] < 1e-2, (li, res[f"tokens_{li}"])
     for k in ("depth", "depth_conf", "world_points", "world_points_conf", "part_feat", "pose_enc"):
         if k in res:
-            assert res[k][1] < 3e-2, (k, res[k])
+            assert res[k][1] < 1e-2 and res[k][0] < 3e-2, (k, res[k])
 
 
 def test_dino_backbone_tokens():
@@ -81,7 +83,7 @@ def test_dino_backbone_tokens():
         out = model.aggregator.patch_embed.forward_features(images)["x_norm_patchtokens"]
         e = errors(out[:, ::m["token_stride"]], g["dino"])
         report(f"dino/{case}", dict(max=e[0], l2=e[1]))
-        assert e[1] < 2e-2, e
+        assert e[1] < 1e-2, e
 
 
 def test_chunked_heads_equal_unchunked():
