@@ -60,24 +60,39 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     const int c_row = lane >> 3, c_pos = lane & 7;
+    // per-lane source pointers of macro tile 0 (row r of each 64-key tile, swizzled piece); later tiles add a
+    // wave-uniform offset, only the last (ragged) macro tile re-derives clamped rows.
+    const bf16_t* ksrc[2];
+    const bf16_t* vsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (2 * wave + i) * 8 + c_row;
+        ksrc[i] = kb_ptr + (long)r * p.k_rs + (c_pos ^ ((r >> 1) & 7)) * 8;
+        vsrc[i] = vb_ptr + (long)r * p.v_rs + ((((c_pos >> 1) ^ (r & 2)) << 1) | (c_pos & 1)) * 8;
+    }
     auto dma = [&](int mt, int buf) {   // macro tile mt -> buffer buf
         char* base = smem + buf * (KVM * BUF_BYTES);
+        const bool ragged = (mt + 1) * (KVM * KV_TILE) > p.Nk;
 #pragma unroll
         for (int sub = 0; sub < KVM; ++sub) {
             char* sK = base + sub * BUF_BYTES;
             char* sV = sK + K_BYTES;
+            const int kv0 = (mt * KVM + sub) * KV_TILE;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int r = (2 * wave + i) * 8 + c_row;  // row within the 64-key tile
-                int kv = (mt * KVM + sub) * KV_TILE + r;
-                kv = kv < p.Nk ? kv : p.Nk - 1;
-                const int kpiece = c_pos ^ ((r >> 1) & 7);
-                const int vpiece = (((c_pos >> 1) ^ (r & 2)) << 1) | (c_pos & 1);
                 const int chunk = (2 * wave + i) * 1024;
-                __builtin_amdgcn_global_load_lds((gptr_t*)(kb_ptr + (long)kv * p.k_rs + kpiece * 8),
-                                                 (lptr_t*)(sK + chunk), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t*)(vb_ptr + (long)kv * p.v_rs + vpiece * 8),
-                                                 (lptr_t*)(sV + chunk), 16, 0, 0);
+                const bf16_t* ks = ksrc[i] + (long)kv0 * p.k_rs;
+                const bf16_t* vs = vsrc[i] + (long)kv0 * p.v_rs;
+                if (ragged) {   // clamp rows past the end to the last valid row (scores are masked to -inf)
+                    const int r = (2 * wave + i) * 8 + c_row;
+                    const int over = kv0 + r - (p.Nk - 1);
+                    if (over > 0) {
+                        ks -= (long)over * p.k_rs;
+                        vs -= (long)over * p.v_rs;
+                    }
+                }
+                __builtin_amdgcn_global_load_lds((gptr_t*)ks, (lptr_t*)(sK + chunk), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t*)vs, (lptr_t*)(sV + chunk), 16, 0, 0);
             }
         }
     };
@@ -98,16 +113,24 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     const int NT = (p.Nk + KV_TILE - 1) / KV_TILE;
 
     // ---- building blocks ---------------------------------------------------------------------
+    // lane-dependent LDS offsets, hoisted: row = (multiple of 32) + frow, so the K swizzle key ((row >> 1) & 7) and the
+    // V chunk flip (row & 2) depend on the lane only; everything else is an immediate.
+    int koff[4], voff[2];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) koff[kc] = frow * 128 + ((((2 * kc + fhalf) ^ (frow >> 1)) & 7) << 4);
+    {
+        const int vr = 4 * fhalf + (tr_i >> 2);
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) voff[dh] = vr * 128 + ((((dh * 2 + tr_g) ^ (vr & 2))) << 5) + 8 * (tr_i & 3);
+    }
     auto qk = [&](const char* sK, int qb, f32x16 (&s)[2]) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kvh = 0; kvh < 2; ++kvh) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kvh][r] = 0.f;
-#pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
-                const bf16x8 kf =
-                    *reinterpret_cast<const bf16x8*>(sK + swz_off(kvh * 32 + frow, 2 * kc + fhalf));
-                s[kvh] = mfma32(kf, qf[qb][kc], s[kvh]);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kvh * 4096 + koff[kc]);
+                s[kvh] = mfma32(kf, qf[qb][kc], kc == 0 ? zero : s[kvh]);
             }
         }
     };
@@ -173,14 +196,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
             for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
                 for (int dh = 0; dh < 2; ++dh) {
-                    const int kvb = kvh * 32 + 16 * cc + 4 * fhalf;
-                    const int row0 = kvb + (tr_i >> 2);
-                    const int chunk = dh * 2 + tr_g;
+                    // keys of this lane half: kvb + {0..3} (elements 0-3) and kvb + 8 + {0..3} (elements 4-7)
                     typedef __attribute__((address_space(3))) short4v lds_s4;
-                    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (lds_s4*)(sV + v_lds_off(row0, chunk) + 8 * (tr_i & 3)));
-                    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (lds_s4*)(sV + v_lds_off(row0 + 8, chunk) + 8 * (tr_i & 3)));
+                    const char* base = sV + (kvh * 32 + 16 * cc) * 128 + voff[dh];
+                    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(base));
+                    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(base + 8 * 128));
                     typedef short short8v __attribute__((ext_vector_type(8)));
                     const short8v v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     o[qb][dh] = mfma32(__builtin_bit_cast(bf16x8, v8), pf[kvh][cc], o[qb][dh]);
