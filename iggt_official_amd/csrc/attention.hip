@@ -471,12 +471,22 @@ extern "C" int iggt_flash_attn_bf16_d64(const void* q, const void* k, const void
     p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.scale_log2 = scale * 1.4426950408889634f;
     if (q_rows_per_wg == 0) {
-        // pick the tile that wastes the fewest padded query rows; ties -> larger tile (more K/V reuse).
-        // Default kernel = v3 (attention_v3.hip: staggered query blocks, deferred max, LDS-DMA staging,
-        // 128-key macro tiles for the 256-row tile): 32-view global attention 805 (v1) -> 860 (v2) -> 930-940 TF/s
-        // (profiles/r01_attn_variants.txt).
+        // Production kernel = v3 (attention_v3.hip).  Tile choice fitted to measurements (probes/attn_tiles.py,
+        // profiles/r01_microbench_kernels.txt): the 256-row tile (2 resident workgroups per CU) is ~10 % faster per
+        // query row, unless (a) it cannot put >= 1.2 rounds of workgroups on the chip -- the per-rank global attention
+        // of an 8-GPU run has 352 -- or (b) it pads the sequence > 5 % more than the 128-row tile (1374-token frames).
+        static int cus = 0;
+        if (cus == 0) {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                      ? prop.multiProcessorCount : 256;
+        }
+        const long w256 = (long)B * H * ((Nq + 255) / 256);
         const int pad256 = ((Nq + 255) / 256) * 256, pad128 = ((Nq + 127) / 128) * 128;
-        q_rows_per_wg = (pad256 <= pad128 + pad128 / 32) ? 6256 : 5128;
+        const bool small_grid = w256 * 10 < (long)cus * 2 * 12;
+        const bool pads_more = (long)pad256 * 100 > (long)pad128 * 105;
+        q_rows_per_wg = (small_grid || pads_more) ? 5128 : 6256;
     }
     if (q_rows_per_wg == 256) {
         p.qtiles = (Nq + 255) / 256;

@@ -148,7 +148,10 @@ extern "C" int iggt_gemm_bf16(const void* A, long lda, const void* W, long ldw, 
     p.accumulate = accumulate; p.act = act;
     p.rows_in = rows_in; p.rows_out = rows_out; p.row_off = row_off;
     // large problems: 256x256 LDS-DMA kernel (gemm_bf16_t256.hip); small / ragged-N ones: this 128x128 kernel
-    if (M >= 1024 && (N % 256) == 0 && force_small_tile() == 0) {
+    // Exception: grids of < 128 big tiles (e.g. N = 1024 with a few thousand rows: the per-rank proj / fc2 GEMMs of an
+    // 8-GPU run) leave most CUs idle -- the 128^2 kernel's 4x finer grid wins there (measured 108 vs 131 us).
+    const long big_tiles = (long)((M + 255) / 256) * (N / 256);
+    if (M >= 1024 && (N % 256) == 0 && big_tiles >= 128 && force_small_tile() == 0) {
         const int rc = iggt_launch_gemm_t256(p, (hipStream_t)stream);
         if (rc == 0) {
             IGGT_CHECK_LAUNCH();

@@ -1,0 +1,34 @@
+"""Emulate one rank of an N-GPU run on a single GPU: the K/V all-gather is replaced by a local repeat (same bytes
+land in the gathered buffer, no transport), so this measures per-rank compute + host launch overhead at N ranks."""
+import os, sys, time
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from iggt.models.vggt import IGGT
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+
+
+class FakeShard:
+    rank, world = 0, N
+
+    def all_gather_kv(self, kv):
+        return kv.repeat(N, 1)
+
+    def all_gather_rows(self, x):
+        return x.repeat(N, *([1] * (x.dim() - 1)))
+
+
+torch.manual_seed(0)
+with torch.device("cuda"):
+    model = IGGT(part_on_invalid_grid="skip").eval()
+model.set_view_shard(FakeShard())
+img = torch.rand(S // N, 3, 518, 518, device="cuda")
+for i in range(4):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    model(img)
+    t_host = time.perf_counter() - t
+    torch.cuda.synchronize(); t_all = time.perf_counter() - t
+    print(f"N={N} local views={S//N}: host-side launch time {t_host*1e3:.1f} ms, forward {t_all*1e3:.1f} ms "
+          f"-> {S/t_all:.1f} views/s if comm were free")
