@@ -145,6 +145,173 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(const GemmParams
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong schedule on the same tile / ring / LDS image.
+//
+// In the kernel above all 8 waves run in lockstep (one barrier per stage), so the two waves that share a SIMD read
+// LDS at the same time and then compete for the matrix pipe, which idles during every read phase.  Here the K loop is
+// cut into phases of one 16-wide k-slice = 6 ds_read_b128 + 8 MFMA (256 matrix-pipe cycles) with TWO barriers per
+// phase, and the wm = 1 waves run one barrier behind the wm = 0 waves:
+//        barrier interval   2j            2j+1          2j+2
+//        wm = 0 waves       read(j)       MFMA(j)       read(j+1)
+//        wm = 1 waves       MFMA(j-1)     read(j)       MFMA(j)
+// so on every SIMD one wave feeds the matrix pipe (at raised priority) while the other fetches its next fragments
+// and issues its share of the DMA.  Stage s+3 is requested in two halves, in phases (s,1) and (s+1,0) -- two phases
+// after the last read of the slot it overwrites -- and stage s+1 is retired by a counted vmcnt(6) in phase (s,1),
+// one phase before its first read (guide: "read a staged buffer one phase AFTER the wait that retires it").
+// DBG: ablation / placement switches (bit 0: no DMA in the loop, bit 1: no fragment reads, bit 2: L2-hot DMA source,
+// bits 3-4: DMA placement).  Production = 16: the A piece of each half is issued in the read interval, the W piece
+// between the MFMAs.  Measured at M=43968, N=1024, K=4096 (TF/s): lockstep kernel 745; ping-pong 789 / 799 / 799 for
+// placement 0 / 1 / 2; L2-hot source 962; no DMA 1258; no fragment reads 808 -> the LDS-DMA path (issue + LDS write
+// ~24 %, L2-miss latency ~18 %) is what separates this kernel from the matrix pipe, not the LDS reads.
+template <int MODE, int DBG>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_t256pp_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = v / p.tiles_n, tn = v - tm * p.tiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    const int c_row = lane >> 2, c_pos = lane & 3;
+    int a_off[2], w_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (2 * wave + i) * 16 + c_row;
+        const int piece = c_pos ^ ((r >> 2) & 3);
+        int ra = m0 + r;
+        ra = ra < p.M ? ra : p.M - 1;
+        int rw = n0 + r;
+        rw = rw < p.N ? rw : p.N - 1;
+        a_off[i] = ra * (int)p.lda + piece * 8;
+        w_off[i] = rw * (int)p.ldw + piece * 8;
+    }
+    // half h of this wave's share of stage kt: one 1-KiB chunk of A and one of W
+    auto dma_a = [&](int kt, int h) {
+        const int ks = (DBG & 4) ? (kt & 1) : kt;  // DBG 4: same DMA instruction stream, L2-hot source
+        __builtin_amdgcn_global_load_lds((gptr_t*)(p.A + a_off[h] + ks * TK),
+                                         (lptr_t*)(smem + (kt & (NSTAGE - 1)) * STAGE_BYTES + (2 * wave + h) * 1024),
+                                         16, 0, 0);
+    };
+    auto dma_w = [&](int kt, int h) {
+        const int ks = (DBG & 4) ? (kt & 1) : kt;
+        __builtin_amdgcn_global_load_lds(
+            (gptr_t*)(p.W + w_off[h] + ks * TK),
+            (lptr_t*)(smem + (kt & (NSTAGE - 1)) * STAGE_BYTES + OP_BYTES + (2 * wave + h) * 1024), 16, 0, 0);
+    };
+    auto dma_half = [&](int kt, int h) {
+        dma_a(kt, h);
+        dma_w(kt, h);
+    };
+    constexpr int PLACE = (DBG >> 3) & 3;  // 0: both DMAs in the read interval, 1: both among the MFMAs, 2: one each
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int KT = p.K / TK;  // >= 4 (launcher)
+    int lane_off[2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) lane_off[kc] = frow * 64 + ((((2 * kc + fhalf) ^ (frow >> 2)) & 3) << 4);
+    const int a_base = wm * 128 * 64, w_base = OP_BYTES + wn * 64 * 64;
+
+    bf16x8 a[4], b[2];
+    auto read6 = [&](const char* st, int kc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 32 * 64 + lane_off[kc]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(st + w_base + j * 32 * 64 + lane_off[kc]);
+    };
+    auto mfma8 = [&](int kt_issue, int h, bool issue) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = q >> 1, j = q & 1;
+            acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+            if (PLACE == 1 && q == 1 && issue) dma_a(kt_issue, h);
+            if (PLACE != 0 && q == 4 && issue) dma_w(kt_issue, h);
+            if (PLACE != 0 && (q == 1 || q == 4)) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // prologue: stages 0, 1 and the first half of stage 2 (10 DMA instructions per wave); stage 0 must land
+    dma_half(0, 0);
+    dma_half(0, 1);
+    dma_half(1, 0);
+    dma_half(1, 1);
+    dma_half(2, 0);
+    wait_vmcnt<6>();
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // the wm = 1 waves run one barrier behind
+
+#pragma unroll 1
+    for (int s = 0; s < KT; ++s) {
+        const char* st = smem + (s & (NSTAGE - 1)) * STAGE_BYTES;
+        const bool i2 = !(DBG & 1) && s + 2 < KT, i3 = !(DBG & 1) && s + 3 < KT;
+        // phase (s, 0): second half of stage s+2
+        if (!(DBG & 2) || s == 0) read6(st, 0);
+        if (i2) {
+            if (PLACE == 0) dma_half(s + 2, 1);
+            if (PLACE == 2) dma_a(s + 2, 1);
+        }
+        mfma8(s + 2, 1, i2);
+        // phase (s, 1): first half of stage s+3, then retire stage s+1
+        if (!(DBG & 2)) read6(st, 1);
+        if (i3) {
+            if (PLACE == 0) dma_half(s + 3, 0);
+            if (PLACE == 2) dma_a(s + 3, 0);
+        }
+        // allowed in flight: stage s+2 (4) + what this phase has issued of stage s+3 so far (2 / 0 / 1)
+        if (s + 3 < KT) wait_vmcnt<(PLACE == 0 ? 6 : PLACE == 1 ? 4 : 5)>();
+        else if (s + 2 < KT) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+        mfma8(s + 3, 0, i3);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();  // even out the barrier count
+
+    wait_vmcnt<0>();
+    __syncthreads();
+    float* stile = reinterpret_cast<float*>(smem);
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stile[(i * 32 + mfma32_row(r, lane)) * TN + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) {
+            const int idx = pass * 512 + tid;
+            const int row = idx >> 6, c4 = idx & 63;
+            const int m = m0 + half * 128 + row;
+            if (m < p.M) {
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(stile + row * TN + c4 * 4);
+                gemm_epilogue_row4<MODE>(p, v4, m, n0 + c4 * 4);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 int iggt_launch_gemm_t256(const GemmParams& p_in, hipStream_t stream) {
@@ -159,18 +326,44 @@ int iggt_launch_gemm_t256(const GemmParams& p_in, hipStream_t stream) {
     else if (p.out_f32 && p.accumulate && p.rows_in == 0 && p.act == 0) mode = 2;
     else if (p.out_f32 && !p.accumulate && p.act == 0 && !p.gamma) mode = 3;
     else return -100;
+    // Production: ping-pong kernel, DMA placement 2 (DBG = 16).  IGGT_GEMM_PP=0 selects the lockstep kernel;
+    // IGGT_GEMM_PPDBG=<bits> (mode-2 GEMMs only) selects an ablation: 1 no DMA in the loop, 4 L2-hot DMA source,
+    // 0 / 8 DMA placement 0 / 1 -- see profiles/r01_gemm_pmc.txt for what they measured.
+    static int pp = -1, ppdbg = -1;
+    if (pp < 0) {
+        const char* e = getenv("IGGT_GEMM_PP");
+        pp = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("IGGT_GEMM_PPDBG");
+        ppdbg = e ? atoi(e) : -1;
+    }
+    const bool use_pp = pp && p.K / TK >= 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_t256_kernel<1>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf16_t256_kernel<2>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf16_t256_kernel<3>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
+        const void* kernels[] = {(const void*)gemm_bf16_t256_kernel<1>,        (const void*)gemm_bf16_t256_kernel<2>,
+                                 (const void*)gemm_bf16_t256_kernel<3>,        (const void*)gemm_bf16_t256pp_kernel<1, 16>,
+                                 (const void*)gemm_bf16_t256pp_kernel<2, 16>,  (const void*)gemm_bf16_t256pp_kernel<3, 16>,
+                                 (const void*)gemm_bf16_t256pp_kernel<2, 0>,   (const void*)gemm_bf16_t256pp_kernel<2, 8>,
+                                 (const void*)gemm_bf16_t256pp_kernel<2, 17>,  (const void*)gemm_bf16_t256pp_kernel<2, 20>};
+        for (const void* k : kernels) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_set = true;
     }
     const dim3 grid(tiles_m * p.tiles_n), block(512);
+    if (use_pp && ppdbg >= 0 && mode == 2) {
+        if (ppdbg == 1) hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<2, 17>), grid, block, lds, stream, p);
+        else if (ppdbg == 4) hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<2, 20>), grid, block, lds, stream, p);
+        else if (ppdbg == 8) hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<2, 8>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<2, 0>), grid, block, lds, stream, p);
+        return 0;
+    }
+    if (use_pp) {
+        if (mode == 1) hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<1, 16>), grid, block, lds, stream, p);
+        else if (mode == 2) hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<2, 16>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<3, 16>), grid, block, lds, stream, p);
+        return 0;
+    }
     if (mode == 1) hipLaunchKernelGGL(gemm_bf16_t256_kernel<1>, grid, block, lds, stream, p);
     else if (mode == 2) hipLaunchKernelGGL(gemm_bf16_t256_kernel<2>, grid, block, lds, stream, p);
     else hipLaunchKernelGGL(gemm_bf16_t256_kernel<3>, grid, block, lds, stream, p);
