@@ -12,7 +12,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -22,15 +22,26 @@ _SIGNATURES = {
     "iggt_gemm_bf16": [_c_void_p, _c_long, _c_void_p, _c_long, _c_int, _c_int, _c_int,
                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int,
                        _c_int, _c_int, _c_int, _c_void_p],
+    "iggt_gemm_f16": [_c_void_p, _c_long, _c_void_p, _c_long, _c_int, _c_int, _c_int,
+                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int,
+                      _c_int, _c_int, _c_int, _c_void_p],
     "iggt_flash_attn_bf16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                                  _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
                                  _c_float, _c_int, _c_void_p],
+    "iggt_flash_attn_f16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                                _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
+                                _c_float, _c_int, _c_void_p],
     "iggt_layernorm_f32": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long,
                            _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p],
     "iggt_qknorm_rope_bf16": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long,
                               _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                               _c_int, _c_int, _c_int, _c_int, _c_float, _c_void_p],
-    "iggt_im2row_patch14": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p],
+    "iggt_qknorm_rope_f16": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long,
+                             _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                             _c_int, _c_int, _c_int, _c_int, _c_float, _c_void_p],
+    "iggt_im2row_patch14": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p],
+    "iggt_colmean_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
+    "iggt_bias_correct_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
     "iggt_conv2d_nhwc_f32": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                              _c_int]
                             + [_c_int] * 24 + [_c_void_p],
@@ -94,44 +105,57 @@ def _dev(*ts):
 
 
 # ------------------------------------------------------------------------------------------------
-# thin typed wrappers
+# thin typed wrappers.  The 16-bit operand format (bf16 or fp16, include/iggt_hip.h) follows the tensors' dtype.
 # ------------------------------------------------------------------------------------------------
-def gemm_bf16(a, w, out, *, bias=None, gamma=None, add_table=None, accumulate=False, act=0,
+H16 = (torch.bfloat16, torch.float16)
+
+
+def _h16(*ts):
+    """Common 16-bit dtype of the given tensors -> symbol suffix ('bf16' | 'f16')."""
+    dt = ts[0].dtype
+    if dt not in H16 or any(t.dtype != dt for t in ts):
+        raise HipExtensionError(f"expected matching bf16 or fp16 operands, got {[str(t.dtype) for t in ts]}")
+    return "f16" if dt == torch.float16 else "bf16"
+
+
+def gemm_h16(a, w, out, *, bias=None, gamma=None, add_table=None, accumulate=False, act=0,
               rows_in=0, rows_out=0, row_off=0, M=None):
-    """out[row(m)] (=|+=) act(a @ w.T + bias) * gamma (+ add_table).  a [M,K] bf16 (row stride ok),
-    w [N,K] bf16, out fp32 or bf16 2-D with unit column stride."""
+    """out[row(m)] (=|+=) act(a @ w.T + bias) * gamma (+ add_table).  a [M,K] and w [N,K] bf16 or fp16 (row
+    stride ok), out fp32 or the operands' 16-bit type, 2-D with unit column stride."""
     _dev(a, w, out, bias, gamma, add_table)
-    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    sfx = _h16(a, w) if out.dtype == torch.float32 else _h16(a, w, out)
     assert a.stride(-1) == 1 and w.stride(-1) == 1 and out.stride(-1) == 1
     M = a.shape[0] if M is None else M
     N, K = w.shape
     assert a.shape[1] == K
     for t in (bias, gamma, add_table):
         assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
-    rc = load().iggt_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), M, N, K,
-                               _ptr(bias), _ptr(gamma), _ptr(add_table), out.data_ptr(), out.stride(0),
-                               int(out.dtype == torch.float32), int(accumulate), act,
-                               rows_in, rows_out, row_off, _stream())
-    _check(rc, "iggt_gemm_bf16")
+    fn = getattr(load(), "iggt_gemm_" + sfx)
+    rc = fn(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), M, N, K,
+            _ptr(bias), _ptr(gamma), _ptr(add_table), out.data_ptr(), out.stride(0),
+            int(out.dtype == torch.float32), int(accumulate), act, rows_in, rows_out, row_off, _stream())
+    _check(rc, "iggt_gemm_" + sfx)
     return out
+
+
+gemm_bf16 = gemm_h16  # historical name (operands may be bf16 or fp16)
 
 
 def flash_attn_d64(q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale,
                    q_rows_per_wg=0):
-    """Token-major attention; q/k/v/o are bf16 tensors (any view) whose data_ptr is element (0,0,0,0)."""
+    """Token-major attention; q/k/v/o are bf16 or fp16 tensors (any view) whose data_ptr is element (0,0,0,0)."""
     _dev(q, k, v, o)
-    for t in (q, k, v, o):
-        assert t.dtype == torch.bfloat16
-    rc = load().iggt_flash_attn_bf16_d64(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Nq, Nk,
-                                         q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, float(scale),
-                                         q_rows_per_wg, _stream())
-    _check(rc, "iggt_flash_attn_bf16_d64")
+    sfx = _h16(q, k, v, o)
+    fn = getattr(load(), f"iggt_flash_attn_{sfx}_d64")
+    rc = fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Nq, Nk,
+            q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, float(scale), q_rows_per_wg, _stream())
+    _check(rc, f"iggt_flash_attn_{sfx}_d64")
     return o
 
 
 def layernorm(x0, w, b, out, eps, *, x1=None, rows=None, rows_in=0, rows_stride=0, row_off=0,
               orows_stride=0, orow_off=0, ldx=None, ldo=None):
-    """LayerNorm over the last dim of x0 (or of concat(x0, x1)); fp32 in, bf16/fp32 out [rows, C]."""
+    """LayerNorm over the last dim of x0 (or of concat(x0, x1)); fp32 in, bf16 / fp16 / fp32 out [rows, C]."""
     _dev(x0, x1, w, b, out)
     assert x0.dtype == torch.float32 and x0.stride(-1) == 1 and out.stride(-1) == 1
     C = x0.shape[-1] * (2 if x1 is not None else 1)
@@ -141,7 +165,7 @@ def layernorm(x0, w, b, out, eps, *, x1=None, rows=None, rows_in=0, rows_stride=
     rc = load().iggt_layernorm_f32(x0.data_ptr(), ld0, _ptr(x1), ld1,
                                    w.data_ptr(), b.data_ptr(), out.data_ptr(),
                                    out.stride(-2) if ldo is None else ldo,
-                                   int(out.dtype == torch.float32), rows, C, float(eps),
+                                   {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}[out.dtype], rows, C, float(eps),
                                    rows_in, rows_stride, row_off, orows_stride, orow_off, _stream())
     _check(rc, "iggt_layernorm_f32")
     return out
@@ -149,21 +173,42 @@ def layernorm(x0, w, b, out, eps, *, x1=None, rows=None, rows_in=0, rows_stride=
 
 def qknorm_rope(qkv, q_out, k_out, v_out, qw, qb, kw, kb, cos_t, sin_t, T, P, gw, patch_start, eps):
     _dev(qkv, q_out, k_out, v_out, qw, cos_t)
-    assert qkv.dtype == torch.bfloat16 and qkv.shape[-1] == 3072
-    rc = load().iggt_qknorm_rope_bf16(qkv.data_ptr(), qkv.stride(0), q_out.data_ptr(), q_out.stride(0),
-                                      k_out.data_ptr(), k_out.stride(0), _ptr(v_out),
-                                      0 if v_out is None else v_out.stride(0),
-                                      qw.data_ptr(), qb.data_ptr(), kw.data_ptr(), kb.data_ptr(),
-                                      cos_t.data_ptr(), sin_t.data_ptr(), T, P, gw, patch_start, float(eps),
-                                      _stream())
-    _check(rc, "iggt_qknorm_rope_bf16")
+    sfx = _h16(qkv, q_out, k_out) if v_out is None else _h16(qkv, q_out, k_out, v_out)
+    assert qkv.shape[-1] == 3072
+    fn = getattr(load(), "iggt_qknorm_rope_" + sfx)
+    rc = fn(qkv.data_ptr(), qkv.stride(0), q_out.data_ptr(), q_out.stride(0),
+            k_out.data_ptr(), k_out.stride(0), _ptr(v_out), 0 if v_out is None else v_out.stride(0),
+            qw.data_ptr(), qb.data_ptr(), kw.data_ptr(), kb.data_ptr(),
+            cos_t.data_ptr(), sin_t.data_ptr(), T, P, gw, patch_start, float(eps), _stream())
+    _check(rc, "iggt_qknorm_rope_" + sfx)
 
 
 def im2row_patch14(img, out, S, H, W, Kpad):
     _dev(img, out)
-    assert img.dtype == torch.float32 and img.is_contiguous() and out.dtype == torch.bfloat16
-    rc = load().iggt_im2row_patch14(img.data_ptr(), out.data_ptr(), S, H, W, Kpad, _stream())
+    assert img.dtype == torch.float32 and img.is_contiguous() and out.dtype in H16
+    rc = load().iggt_im2row_patch14(img.data_ptr(), out.data_ptr(), int(out.dtype == torch.float16), S, H, W, Kpad,
+                                    _stream())
     _check(rc, "iggt_im2row_patch14")
+    return out
+
+
+def colmean(x, mu, row_step=1):
+    """mu[k] = mean of x[::row_step, k]; x 16-bit [rows, K] (row stride ok), mu fp32 [K]."""
+    _dev(x, mu)
+    assert x.dtype in H16 and x.stride(-1) == 1 and mu.dtype == torch.float32 and mu.is_contiguous()
+    rc = load().iggt_colmean_h16(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], row_step,
+                                 int(x.dtype == torch.float16), mu.data_ptr(), _stream())
+    _check(rc, "iggt_colmean_h16")
+    return mu
+
+
+def bias_correct(dw, mu, bias, out):
+    """out = (bias or 0) + dw @ mu; dw 16-bit [N, K], mu fp32 [K], bias / out fp32 [N]."""
+    _dev(dw, mu, bias, out)
+    assert dw.dtype in H16 and dw.stride(-1) == 1 and mu.dtype == torch.float32 and out.dtype == torch.float32
+    rc = load().iggt_bias_correct_h16(dw.data_ptr(), dw.stride(0), dw.shape[0], dw.shape[1], mu.data_ptr(),
+                                      _ptr(bias), out.data_ptr(), int(dw.dtype == torch.float16), _stream())
+    _check(rc, "iggt_bias_correct_h16")
     return out
 
 

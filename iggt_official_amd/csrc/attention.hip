@@ -457,10 +457,9 @@ __global__ __launch_bounds__(512, 2) void flash_attn_d64_pp_kernel(const AttnPar
 
 }  // namespace
 
-extern "C" int iggt_flash_attn_bf16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
-                                        int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
-                                        long v_bs, long v_rs, long o_bs, long o_rs, float scale,
-                                        int q_rows_per_wg, void* stream) {
+static int flash_attn_h16(int fmt, const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
+                          long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs, long o_rs,
+                          float scale, int q_rows_per_wg, void* stream) {
     if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return -1;
     if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (o_rs % 4)) return -2;
     if ((q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 4)) return -2;
@@ -488,14 +487,16 @@ extern "C" int iggt_flash_attn_bf16_d64(const void* q, const void* k, const void
         const bool pads_more = (long)pad256 * 100 > (long)pad128 * 105;
         q_rows_per_wg = (small_grid || pads_more) ? 5128 : 6256;
     }
+    const bool v3 = q_rows_per_wg == 5128 || q_rows_per_wg == 5256 || q_rows_per_wg == 6128 || q_rows_per_wg == 6256;
+    if (fmt != FMT_BF16 && !v3) return -4;  // the earlier kernel generations (128 / 256 / 512) are bf16-only
     if (q_rows_per_wg == 256) {
         p.qtiles = (Nq + 255) / 256;
         hipLaunchKernelGGL(flash_attn_d64_kernel<2>, dim3(B * H * p.qtiles), dim3(256), 0, (hipStream_t)stream, p);
     } else if (q_rows_per_wg == 128) {
         p.qtiles = (Nq + 127) / 128;
         hipLaunchKernelGGL(flash_attn_d64_kernel<1>, dim3(B * H * p.qtiles), dim3(256), 0, (hipStream_t)stream, p);
-    } else if (q_rows_per_wg == 5128 || q_rows_per_wg == 5256 || q_rows_per_wg == 6128 || q_rows_per_wg == 6256) {
-        iggt_launch_flash_attn_v3(p, q_rows_per_wg % 1000, q_rows_per_wg / 1000 - 4, (hipStream_t)stream);
+    } else if (v3) {
+        iggt_launch_flash_attn_v3(p, q_rows_per_wg % 1000, q_rows_per_wg / 1000 - 4, fmt, (hipStream_t)stream);
     } else if (q_rows_per_wg == 512) {
         p.qtiles = (Nq + 511) / 512;
         hipLaunchKernelGGL(flash_attn_d64_pp_kernel<2>, dim3(B * H * p.qtiles), dim3(512), 0, (hipStream_t)stream, p);
@@ -504,4 +505,20 @@ extern "C" int iggt_flash_attn_bf16_d64(const void* q, const void* k, const void
     }
     IGGT_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int iggt_flash_attn_bf16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
+                                        int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
+                                        long v_bs, long v_rs, long o_bs, long o_rs, float scale,
+                                        int q_rows_per_wg, void* stream) {
+    return flash_attn_h16(FMT_BF16, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale,
+                          q_rows_per_wg, stream);
+}
+
+extern "C" int iggt_flash_attn_f16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
+                                       int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
+                                       long v_bs, long v_rs, long o_bs, long o_rs, float scale,
+                                       int q_rows_per_wg, void* stream) {
+    return flash_attn_h16(FMT_F16, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale,
+                          q_rows_per_wg, stream);
 }

@@ -28,8 +28,20 @@ IGGT_DEVINL bf16x8 pack8(const f32x16& s, int base) {
     return r;
 }
 
+// softmax numerators -> packed operand fragment (no saturation: P <= 2^(DEFER_THR + P_SHIFT))
+template <int FMT>
+IGGT_DEVINL bf16x8 pack8h(const f32x16& s, int base) {
+    u32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = pack_h2<FMT, false>(s[base + 2 * j], s[base + 2 * j + 1]);
+    return __builtin_bit_cast(bf16x8, r);
+}
+// fp16 operands: the numerators are computed as 2^(s - m + P_SHIFT) so that entries far below the row maximum stay
+// in fp16's normal range (smallest normal 6.1e-5 * 2^-8 = 2.4e-7 of the maximum, subnormals to 2.3e-10); the
+// shift cancels in O / l.  bf16 has fp32's exponent range and needs none.
+constexpr float P_SHIFT_F16 = 8.0f;
 
 }  // namespace iggt_attn
 
 // experimental variants live in their own translation units
-int iggt_launch_flash_attn_v3(const iggt_attn::AttnParams& p, int q_rows, int kvm, hipStream_t stream);
+int iggt_launch_flash_attn_v3(const iggt_attn::AttnParams& p, int q_rows, int kvm, int fmt, hipStream_t stream);

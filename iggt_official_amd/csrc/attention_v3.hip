@@ -26,7 +26,7 @@ namespace {
 
 constexpr float DEFER_THR = 4.0f;  // log2 units: P <= 16
 
-template <int QB, int KVM>
+template <int QB, int KVM, int FMT>
 __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KVM * BUF_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kvh * 4096 + koff[kc]);
-                s[kvh] = mfma32(kf, qf[qb][kc], kc == 0 ? zero : s[kvh]);
+                s[kvh] = mfma32h<FMT>(kf, qf[qb][kc], kc == 0 ? zero : s[kvh]);
             }
         }
     };
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         }
     };
     auto exp_pack = [&](int qb, f32x16 (&s)[2], bf16x8 (&pf)[2][2]) {
-        const float m = m_run[qb];
+        const float m = m_run[qb] - (FMT == FMT_F16 ? P_SHIFT_F16 : 0.f);
         float ls0 = 0.f, ls1 = 0.f, ls2 = 0.f, ls3 = 0.f;
 #pragma unroll
         for (int kvh = 0; kvh < 2; ++kvh) {
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                 ls2 += s[kvh][r + 2];
                 ls3 += s[kvh][r + 3];
             }
-            pf[kvh][0] = pack8(s[kvh], 0);
-            pf[kvh][1] = pack8(s[kvh], 8);
+            pf[kvh][0] = pack8h<FMT>(s[kvh], 0);
+            pf[kvh][1] = pack8h<FMT>(s[kvh], 8);
         }
         l_run[qb] += (ls0 + ls1) + (ls2 + ls3);
     };
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                     const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(base + 8 * 128));
                     typedef short short8v __attribute__((ext_vector_type(8)));
                     const short8v v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[qb][dh] = mfma32(__builtin_bit_cast(bf16x8, v8), pf[kvh][cc], o[qb][dh]);
+                    o[qb][dh] = mfma32h<FMT>(__builtin_bit_cast(bf16x8, v8), pf[kvh][cc], o[qb][dh]);
                 }
     };
 
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     u32x2 w;
-                    w[0] = pack_bf16x2(o[qb][dh][4 * g + 0] * inv, o[qb][dh][4 * g + 1] * inv);
-                    w[1] = pack_bf16x2(o[qb][dh][4 * g + 2] * inv, o[qb][dh][4 * g + 3] * inv);
+                    w[0] = pack_h2<FMT>(o[qb][dh][4 * g + 0] * inv, o[qb][dh][4 * g + 1] * inv);
+                    w[1] = pack_h2<FMT>(o[qb][dh][4 * g + 2] * inv, o[qb][dh][4 * g + 3] * inv);
                     *reinterpret_cast<u32x2*>(dst + dh * 32 + 8 * g) = w;
                 }
         }
@@ -264,18 +264,24 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
 }  // namespace
 
 // Launched from iggt_flash_attn_bf16_d64 (attention.hip): code = 256 | 128 (q rows per WG) + 1000 * KVM.
-int iggt_launch_flash_attn_v3(const AttnParams& p_in, int q_rows, int kvm, hipStream_t stream) {
+template <int FMT>
+static void launch_v3(const AttnParams& p_in, int q_rows, int kvm, hipStream_t stream) {
     AttnParams p = p_in;
     if (q_rows == 256) {
         p.qtiles = (p.Nq + 255) / 256;
         const dim3 grid(p.B * p.H * p.qtiles), block(256);
-        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 1>), grid, block, 0, stream, p);
+        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2, FMT>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 1, FMT>), grid, block, 0, stream, p);
     } else {
         p.qtiles = (p.Nq + 127) / 128;
         const dim3 grid(p.B * p.H * p.qtiles), block(256);
-        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 2>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 1>), grid, block, 0, stream, p);
+        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 2, FMT>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 1, FMT>), grid, block, 0, stream, p);
     }
+}
+
+int iggt_launch_flash_attn_v3(const AttnParams& p, int q_rows, int kvm, int fmt, hipStream_t stream) {
+    if (fmt == FMT_F16) launch_v3<FMT_F16>(p, q_rows, kvm, stream);
+    else launch_v3<FMT_BF16>(p, q_rows, kvm, stream);
     return 0;
 }

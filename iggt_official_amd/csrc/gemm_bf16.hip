@@ -1,4 +1,4 @@
-// bf16 MFMA GEMM with fused epilogues for the IGGT linear layers.
+// 16-bit-operand (bf16 / fp16, template FMT) MFMA GEMM with fused epilogues for the IGGT linear layers.
 //
 //   C[m][n] = sum_k A[m][k] * W[n][k]        A: [M,K] bf16 row-major (lda), W: [N,K] bf16 (ldw)
 //
@@ -28,6 +28,7 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per buffer
 
+template <int FMT>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32h<FMT>(a[i], b[j], acc[i][j]);
         }
         if (kt + 1 < KT) swrite((kt + 1) & 1);
         __syncthreads();
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + (lane & 31);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) gemm_epilogue_tile<0>(p, acc[i][j], m0 + wm * 64 + i * 32, n, lane);
+        for (int i = 0; i < 2; ++i) gemm_epilogue_tile<0, FMT>(p, acc[i][j], m0 + wm * 64 + i * 32, n, lane);
     }
 }
 
@@ -127,10 +128,9 @@ static int force_small_tile() {
     return v;
 }
 
-extern "C" int iggt_gemm_bf16(const void* A, long lda, const void* W, long ldw, int M, int N, int K,
-                              const float* bias, const float* gamma, const float* add_table,
-                              void* out, long ldo, int out_is_f32, int accumulate, int act,
-                              int rows_in, int rows_out, int row_off, void* stream) {
+static int gemm_h16(int fmt, const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
+                    const float* gamma, const float* add_table, void* out, long ldo, int out_is_f32, int accumulate,
+                    int act, int rows_in, int rows_out, int row_off, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0) return -1;
     if ((lda % 8) != 0 || (ldw % 8) != 0) return -2;  // 16-B aligned operand rows
     if (accumulate && !out_is_f32) return -3;
@@ -152,7 +152,7 @@ extern "C" int iggt_gemm_bf16(const void* A, long lda, const void* W, long ldw, 
     // 8-GPU run) leave most CUs idle -- the 128^2 kernel's 4x finer grid wins there (measured 108 vs 131 us).
     const long big_tiles = (long)((M + 255) / 256) * (N / 256);
     if (M >= 1024 && (N % 256) == 0 && big_tiles >= 128 && force_small_tile() == 0) {
-        const int rc = iggt_launch_gemm_t256(p, (hipStream_t)stream);
+        const int rc = iggt_launch_gemm_t256(p, fmt, (hipStream_t)stream);
         if (rc == 0) {
             IGGT_CHECK_LAUNCH();
             return 0;
@@ -163,12 +163,32 @@ extern "C" int iggt_gemm_bf16(const void* A, long lda, const void* W, long ldw, 
     const int lds = 2 * 2 * TILE_BYTES;  // 64 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<FMT_BF16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<FMT_F16>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tiles_m * p.tiles_n), dim3(256), lds, (hipStream_t)stream, p);
+    const dim3 grid(tiles_m * p.tiles_n), block(256);
+    if (fmt == FMT_F16) hipLaunchKernelGGL(gemm_bf16_kernel<FMT_F16>, grid, block, lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_bf16_kernel<FMT_BF16>, grid, block, lds, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int iggt_gemm_bf16(const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+                              const float* bias, const float* gamma, const float* add_table,
+                              void* out, long ldo, int out_is_f32, int accumulate, int act,
+                              int rows_in, int rows_out, int row_off, void* stream) {
+    return gemm_h16(FMT_BF16, A, lda, W, ldw, M, N, K, bias, gamma, add_table, out, ldo, out_is_f32, accumulate, act,
+                    rows_in, rows_out, row_off, stream);
+}
+
+extern "C" int iggt_gemm_f16(const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+                             const float* bias, const float* gamma, const float* add_table,
+                             void* out, long ldo, int out_is_f32, int accumulate, int act,
+                             int rows_in, int rows_out, int row_off, void* stream) {
+    return gemm_h16(FMT_F16, A, lda, W, ldw, M, N, K, bias, gamma, add_table, out, ldo, out_is_f32, accumulate, act,
+                    rows_in, rows_out, row_off, stream);
 }

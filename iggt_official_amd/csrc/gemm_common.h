@@ -13,7 +13,7 @@ struct GemmParams {
     const float* gamma;      // [N] or null
     const float* add_table;  // [rows_in][N] fp32 or null, indexed by (m % rows_in)
     float* out_f32;          // exactly one of out_f32 / out_bf16
-    bf16_t* out_bf16;
+    bf16_t* out_bf16;        // 16-bit output (bf16 or fp16 container, see the kernels' FMT)
     long ldo;
     int accumulate;  // out_f32 += value
     int act;         // 0 none, 1 exact GELU, 2 ReLU
@@ -40,7 +40,7 @@ IGGT_DEVINL float gelu_erf(float x) {
 // MODE 0: every feature (runtime flags).  Specialised modes keep the inlined code (and with it the register
 // allocation of the big-tile kernel) small:  1 = bf16 out, bias + act;  2 = fp32 accumulate, bias + gamma;
 // 3 = fp32 store, bias (+ row remap / additive table).
-template <int MODE>
+template <int MODE, int FMT>
 IGGT_DEVINL void gemm_epilogue_tile(const GemmParams& p, const f32x16& acc, int m_base, int n, int lane) {
     if (n >= p.N) return;
     const float bias = p.bias ? p.bias[n] : 0.f;
@@ -64,7 +64,7 @@ IGGT_DEVINL void gemm_epilogue_tile(const GemmParams& p, const f32x16& acc, int 
             }
         }
         if (MODE == 1) {
-            p.out_bf16[orow * p.ldo + n] = (bf16_t)val;
+            reinterpret_cast<uint16_t*>(p.out_bf16)[orow * p.ldo + n] = pack_h1<FMT>(val);
         } else if (MODE == 2) {
             float* dst = p.out_f32 + orow * p.ldo + n;
             *dst = *dst + val;
@@ -74,13 +74,13 @@ IGGT_DEVINL void gemm_epilogue_tile(const GemmParams& p, const f32x16& acc, int 
             float* dst = p.out_f32 + orow * p.ldo + n;
             *dst = p.accumulate ? (*dst + val) : val;
         } else {
-            p.out_bf16[orow * p.ldo + n] = (bf16_t)val;
+            reinterpret_cast<uint16_t*>(p.out_bf16)[orow * p.ldo + n] = pack_h1<FMT>(val);
         }
     }
 }
 
 // Same epilogue on 4 consecutive columns n..n+3 of row m (vector loads/stores; N % 4 == 0, n + 3 < N).
-template <int MODE>
+template <int MODE, int FMT>
 IGGT_DEVINL void gemm_epilogue_row4(const GemmParams& p, f32x4 v, int m, int n) {
     if (p.bias) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
@@ -96,8 +96,8 @@ IGGT_DEVINL void gemm_epilogue_row4(const GemmParams& p, f32x4 v, int m, int n) 
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         u32x2 o;
-        o[0] = pack_bf16x2(v[0], v[1]);
-        o[1] = pack_bf16x2(v[2], v[3]);
+        o[0] = pack_h2<FMT>(v[0], v[1]);
+        o[1] = pack_h2<FMT>(v[2], v[3]);
         *reinterpret_cast<u32x2*>(p.out_bf16 + (long)m * p.ldo + n) = o;
     } else if (MODE == 2) {
         if (p.gamma) {
@@ -126,4 +126,4 @@ IGGT_DEVINL void gemm_epilogue_row4(const GemmParams& p, f32x4 v, int m, int n) 
 }
 
 // returns -100 when the parameter combination has no specialised big-tile kernel (caller falls back)
-int iggt_launch_gemm_t256(const GemmParams& p, hipStream_t stream);
+int iggt_launch_gemm_t256(const GemmParams& p, int fmt, hipStream_t stream);

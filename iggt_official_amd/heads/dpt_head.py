@@ -24,8 +24,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _C
-from ..layers.blocks import Workspace
+from .. import _C, precision
+from ..layers.blocks import Workspace, compensated_bias
 from . import convops as co
 from .head_act import inverse_log_transform
 from .utils import pos_embed_map, pos_embed_rows
@@ -108,10 +108,12 @@ class TokenProjector:
 
     def packed(self, idx, conv: nn.Conv2d):
         w = conv.weight
-        key = (w.data_ptr(), w._version)
+        dt = precision.operand_dtype()
+        key = (w.data_ptr(), w._version, dt, precision.mean_compensation())
         if self._pk.get(idx, (None,))[0] != key:
-            self._pk[idx] = (key, w.detach().reshape(w.shape[0], -1).to(torch.bfloat16).contiguous(),
-                             conv.bias.detach().float().contiguous())
+            w2 = w.detach().reshape(w.shape[0], -1).float()
+            dw = (w2 - w2.to(dt).float()).to(dt).contiguous() if precision.mean_compensation() else None
+            self._pk[idx] = (key, w2.to(dt).contiguous(), conv.bias.detach().float().contiguous(), dw)
         return self._pk[idx][1:]
 
     def __call__(self, tokens, s0, s1, psi, gh, gw, norm: nn.LayerNorm, idx, conv: nn.Conv2d, pos_table=None):
@@ -122,12 +124,13 @@ class TokenProjector:
         S, g2 = s1 - s0, gh * gw
         t = tokens[0, s0:s1]
         assert t.is_contiguous() and P == psi + g2
-        xn = self.ws.get("xn", (S * g2, C2), torch.bfloat16, tokens.device)
+        w, b, dw = self.packed(idx, conv)
+        xn = self.ws.get("xn", (S * g2, C2), w.dtype, tokens.device)
         _C.layernorm(t.reshape(S * P, C2), norm.weight.detach().float(), norm.bias.detach().float(), xn,
                      norm.eps, rows=S * g2, rows_in=g2, rows_stride=P, row_off=psi)
-        w, b = self.packed(idx, conv)
         out = torch.empty(S * g2, w.shape[0], dtype=torch.float32, device=tokens.device)
-        _C.gemm_bf16(xn, w, out, bias=b, add_table=pos_table, rows_in=g2, rows_out=g2, row_off=0)
+        _C.gemm_h16(xn, w, out, bias=compensated_bias(self.ws, xn, dw, b), add_table=pos_table, rows_in=g2, rows_out=g2,
+                    row_off=0)
         return out.view(S, gh, gw, w.shape[0])
 
 

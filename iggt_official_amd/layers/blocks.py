@@ -5,8 +5,9 @@ block.py:27-107,210-259}.  Parameters stay fp32 `nn.Parameter`s under the refere
 keys (checkpoint contract); bf16 MFMA copies of the GEMM weights are packed
 lazily (`packed()`), keyed on the parameter version so `load_state_dict` / `.to()` invalidate them.
 
-Numerics = the reference's GPU mode (demo.py:193-195, autocast bf16): LayerNorm, q/k-norm, RoPE,
-LayerScale and the residual stream in fp32; GEMM and attention operands bf16 with fp32 accumulate.
+Numerics: LayerNorm, q/k-norm, RoPE, LayerScale and the residual stream in fp32; GEMM and attention operands
+16-bit with fp32 accumulate -- fp16 by default, bf16 (the reference's autocast GPU mode, demo.py:193-195) on request
+(iggt_official_amd/precision.py).
 
 Execution is in place on a flat fp32 token matrix x[T, C] (`Block.forward_inplace`); the
 `forward(x, pos)` signatures of the reference are kept as thin wrappers.
@@ -16,7 +17,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from .. import _C, profiling
+from .. import _C, precision, profiling
 
 
 class LayerScale(nn.Module):
@@ -90,13 +91,34 @@ class Workspace:
         return self.get(name, (rows, cols + pad), dtype, device)[:, :cols]
 
 
-def _bf16_weight(lin: nn.Linear, pad: int = 0):
-    w = lin.weight.detach().to(torch.bfloat16)
+def _h16_weight(lin: nn.Linear, dt: torch.dtype, pad: int = 0):
+    w = lin.weight.detach().to(dt)
     if pad == 0:
         return w.contiguous()
-    buf = torch.zeros(w.shape[0], w.shape[1] + pad, dtype=torch.bfloat16, device=w.device)
+    buf = torch.zeros(w.shape[0], w.shape[1] + pad, dtype=dt, device=w.device)
     buf[:, :w.shape[1]] = w
     return buf[:, :w.shape[1]]
+
+
+def _h16_residual(lin: nn.Linear, dt: torch.dtype):
+    """dW = W - round16(W), itself stored in 16 bits (mean-input compensation, csrc/elementwise.hip)."""
+    w = lin.weight.detach().float()
+    return (w - w.to(dt).float()).to(dt).contiguous()
+
+
+MEAN_SAMPLE_ROWS = 2048  # the column mean is taken over ~this many evenly spaced rows (sampling error 1/45 sigma)
+
+
+def compensated_bias(ws: "Workspace", a: torch.Tensor, dw: Optional[torch.Tensor], bias: Optional[torch.Tensor]):
+    """bias + dW mean_rows(a): restores the part of the weight rounding that is common to all tokens
+    (precision.py); `bias` itself when compensation is off."""
+    if dw is None:
+        return bias
+    N, K = dw.shape
+    mu = ws.get("mean_in", (K,), torch.float32, a.device)
+    out = ws.get("bias_comp", (N,), torch.float32, a.device)
+    _C.colmean(a, mu, max(1, a.shape[0] // MEAN_SAMPLE_ROWS))
+    return _C.bias_correct(dw, mu, bias, out)
 
 
 class Block(nn.Module):
@@ -122,23 +144,29 @@ class Block(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def packed(self):
-        """bf16 copies of the four GEMM weights + fp32 epilogue vectors, rebuilt when params change."""
+        """16-bit (precision.operand_dtype()) copies of the four GEMM weights + fp32 epilogue vectors, rebuilt when
+        params or the operand format change."""
         ps = (self.attn.qkv.weight, self.attn.proj.weight, self.mlp.fc1.weight, self.mlp.fc2.weight)
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        dt = precision.operand_dtype()
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (dt, precision.mean_compensation())
         if self._packed_key != key:
             dev = ps[0].device
             f32 = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
             ones = lambda: torch.ones(self.dim, device=dev)  # noqa: E731
             self._packed = dict(
-                w_qkv=_bf16_weight(self.attn.qkv, ROW_PAD), b_qkv=f32(self.attn.qkv.bias),
-                w_proj=_bf16_weight(self.attn.proj), b_proj=f32(self.attn.proj.bias),
-                w_fc1=_bf16_weight(self.mlp.fc1), b_fc1=f32(self.mlp.fc1.bias),
-                w_fc2=_bf16_weight(self.mlp.fc2), b_fc2=f32(self.mlp.fc2.bias),
+                w_qkv=_h16_weight(self.attn.qkv, dt, ROW_PAD), b_qkv=f32(self.attn.qkv.bias),
+                w_proj=_h16_weight(self.attn.proj, dt), b_proj=f32(self.attn.proj.bias),
+                w_fc1=_h16_weight(self.mlp.fc1, dt), b_fc1=f32(self.mlp.fc1.bias),
+                w_fc2=_h16_weight(self.mlp.fc2, dt), b_fc2=f32(self.mlp.fc2.bias),
                 g1=f32(self.ls1.gamma) if isinstance(self.ls1, LayerScale) else ones(),
                 g2=f32(self.ls2.gamma) if isinstance(self.ls2, LayerScale) else ones(),
                 n1w=f32(self.norm1.weight), n1b=f32(self.norm1.bias),
                 n2w=f32(self.norm2.weight), n2b=f32(self.norm2.bias),
             )
+            comp = precision.mean_compensation()
+            for n, lin in (("qkv", self.attn.qkv), ("proj", self.attn.proj), ("fc1", self.mlp.fc1),
+                           ("fc2", self.mlp.fc2)):
+                self._packed["dw_" + n] = _h16_residual(lin, dt) if comp else None
             if self.attn.qk_norm:
                 self._packed.update(qw=f32(self.attn.q_norm.weight), qb=f32(self.attn.q_norm.bias),
                                     kw=f32(self.attn.k_norm.weight), kb=f32(self.attn.k_norm.bias))
@@ -165,13 +193,14 @@ class Block(nn.Module):
         dev = x2d.device
         pk = self.packed()
         H = self.attn.num_heads
-        xn = ws.get_padded("xn", T, C, torch.bfloat16, dev)
-        qkv = ws.get("qkv", (T, 3 * C), torch.bfloat16, dev)
-        ao = ws.get("ao", (T, C), torch.bfloat16, dev)
-        hid = ws.get("hid", (T, pk["w_fc1"].shape[0]), torch.bfloat16, dev)
+        dt = pk["w_qkv"].dtype  # 16-bit operand format of this forward
+        xn = ws.get_padded("xn", T, C, dt, dev)
+        qkv = ws.get("qkv", (T, 3 * C), dt, dev)
+        ao = ws.get("ao", (T, C), dt, dev)
+        hid = ws.get("hid", (T, pk["w_fc1"].shape[0]), dt, dev)
 
         _C.layernorm(x2d, pk["n1w"], pk["n1b"], xn, self.norm1.eps)
-        _C.gemm_bf16(xn, pk["w_qkv"], qkv, bias=pk["b_qkv"])
+        _C.gemm_h16(xn, pk["w_qkv"], qkv, bias=compensated_bias(ws, xn, pk["dw_qkv"], pk["b_qkv"]))
         k_src, v_src, kv_rs, Nk, k_bs = qkv[:, C:], qkv[:, 2 * C:], 3 * C, tokens, tokens * 3 * C
         if self.attn.qk_norm:
             assert rope_geom is not None
@@ -180,7 +209,7 @@ class Block(nn.Module):
                                rope_geom["cos"], rope_geom["sin"], T, rope_geom["P"], rope_geom["gw"],
                                rope_geom["patch_start"], self.attn.q_norm.eps)
             else:
-                kv_local = ws.get("kv_local", (T, 2 * C), torch.bfloat16, dev)
+                kv_local = ws.get("kv_local", (T, 2 * C), dt, dev)
                 _C.qknorm_rope(qkv, qkv, kv_local, kv_local[:, C:], pk["qw"], pk["qb"], pk["kw"], pk["kb"],
                                rope_geom["cos"], rope_geom["sin"], T, rope_geom["P"], rope_geom["gw"],
                                rope_geom["patch_start"], self.attn.q_norm.eps)
@@ -193,10 +222,12 @@ class Block(nn.Module):
             _C.flash_attn_d64(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
                               tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,
                               self.attn.scale, q_rows_per_wg)
-        _C.gemm_bf16(ao, pk["w_proj"], x2d, bias=pk["b_proj"], gamma=pk["g1"], accumulate=True)
+        _C.gemm_h16(ao, pk["w_proj"], x2d, bias=compensated_bias(ws, ao, pk["dw_proj"], pk["b_proj"]), gamma=pk["g1"],
+                    accumulate=True)
         _C.layernorm(x2d, pk["n2w"], pk["n2b"], xn, self.norm2.eps)
-        _C.gemm_bf16(xn, pk["w_fc1"], hid, bias=pk["b_fc1"], act=1)
-        _C.gemm_bf16(hid, pk["w_fc2"], x2d, bias=pk["b_fc2"], gamma=pk["g2"], accumulate=True)
+        _C.gemm_h16(xn, pk["w_fc1"], hid, bias=compensated_bias(ws, xn, pk["dw_fc1"], pk["b_fc1"]), act=1)
+        _C.gemm_h16(hid, pk["w_fc2"], x2d, bias=compensated_bias(ws, hid, pk["dw_fc2"], pk["b_fc2"]), gamma=pk["g2"],
+                    accumulate=True)
         return x2d
 
     def forward(self, x: torch.Tensor, pos=None) -> torch.Tensor:

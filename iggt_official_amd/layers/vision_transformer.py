@@ -19,8 +19,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _C
-from .blocks import Block, MemEffAttention, Mlp, Workspace
+from .. import _C, precision
+from .blocks import Block, MemEffAttention, Mlp, Workspace, compensated_bias
 from .patch_embed import PatchEmbed
 
 KPAD = 640  # 3*14*14 = 588 taps padded to a multiple of the GEMM K-tile (64)
@@ -97,12 +97,18 @@ class DinoVisionTransformer(nn.Module):
 
     def _packed_patch_weight(self):
         w = self.patch_embed.proj.weight
-        key = (w.data_ptr(), w._version)
+        dt = precision.operand_dtype()
+        key = (w.data_ptr(), w._version, dt, precision.mean_compensation())
         if self._cache.get("pw_key") != key:
-            wp = torch.zeros(w.shape[0], KPAD, dtype=torch.bfloat16, device=w.device)
-            wp[:, : w[0].numel()] = w.detach().reshape(w.shape[0], -1).to(torch.bfloat16)
+            w2 = w.detach().reshape(w.shape[0], -1).float()
+            wp = torch.zeros(w.shape[0], KPAD, dtype=dt, device=w.device)
+            wp[:, : w2.shape[1]] = w2.to(dt)
+            dwp = None
+            if precision.mean_compensation():   # dW = W - round16(W) for the mean-input compensation (blocks.py)
+                dwp = torch.zeros_like(wp)
+                dwp[:, : w2.shape[1]] = (w2 - w2.to(dt).float()).to(dt)
             self._cache["pw_key"] = key
-            self._cache["pw"] = (wp, self.patch_embed.proj.bias.detach().float().contiguous())
+            self._cache["pw"] = (wp, self.patch_embed.proj.bias.detach().float().contiguous(), dwp)
         return self._cache["pw"]
 
     # ---- fused forward ---------------------------------------------------------------------------
@@ -123,11 +129,11 @@ class DinoVisionTransformer(nn.Module):
         dev = images.device
         images = images.contiguous().float()
         special, patch_pe = self._pos_tables(H, W)
-        wp, bias = self._packed_patch_weight()
-        a = self._ws.get("im2row", (S * g2, KPAD), torch.bfloat16, dev)
+        wp, bias, dwp = self._packed_patch_weight()
+        a = self._ws.get("im2row", (S * g2, KPAD), wp.dtype, dev)
         _C.im2row_patch14(images, a, S, H, W, KPAD)
         x = torch.empty(S, P, D, dtype=torch.float32, device=dev)
-        _C.gemm_bf16(a, wp, x.view(S * P, D), bias=bias, add_table=patch_pe,
+        _C.gemm_h16(a, wp, x.view(S * P, D), bias=compensated_bias(self._ws, a, dwp, bias), add_table=patch_pe,
                      rows_in=g2, rows_out=P, row_off=nsp)
         _C.write_special_tokens(x, special, special, S, nsp, 0, False)
         x2d = x.view(S * P, D)

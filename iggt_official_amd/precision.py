@@ -1,0 +1,61 @@
+"""16-bit operand format of the trunk GEMM / attention kernels (include/iggt_hip.h).
+
+The reference's GPU mode is autocast(bfloat16) (demo.py:190-193); its documented output, and the parity
+target of this repository, is the fp32 CPU path.  bf16 operands (8 significant bits) put the aggregated tokens
+6.5e-3 (relative l2) away from fp32; IEEE half (11 bits) at the same MFMA rate brings that to 8e-4
+(oracle/precision_sim.py), inside the 1e-3 target, so fp16 is the default.  Everything that is not an MFMA operand --
+accumulation, LayerNorm, q/k-norm, RoPE, softmax statistics, LayerScale, the residual stream, the dense heads -- is
+fp32 in both modes.  fp16 stores saturate at +-65504 (csrc/common.h pack_h2); LayerNorm outputs, q/k/v, attention
+outputs and GELU activations of a ViT-L are orders of magnitude below that.
+
+Of the eight rounding sites of a block (oracle/precision_sim.py --ablate) the WEIGHTS dominate the fp16 error: their
+rounding is the same for every token, so it does not average out (tokens 8.6e-4 -> 3.8e-4 with exact weights; the
+seven activation sites together matter less than the weights of any one GEMM).  Almost all of that is the response
+to the MEAN input vector: x W^T = x Wh^T + mu dW^T + (x - mu) dW^T with Wh = round16(W), dW = W - Wh, mu = mean over
+tokens of the GEMM input.  "Mean-input compensation" restores the middle term exactly: a column mean over ~2048 evenly
+spaced rows of the input and one small matrix-vector product give b' = b + dW mu, which replaces the bias of the GEMM
+(csrc/elementwise.hip colmean / bias_correct; layers/blocks.py compensated_bias).  Simulated token error 8.6e-4 ->
+4.3e-4 for two tiny kernels per GEMM (~1.5 % of the step).  On with fp16 operands, off in bf16 mode, which keeps the
+reference's autocast arithmetic; IGGT_MEAN_COMP=0 turns it off.  With view sharding each rank uses the mean of its
+own rows (no collective): results then differ between shardings by O(1e-4) relative, inside the tolerance.
+
+    IGGT_OPERAND_DTYPE=bf16|f16      environment override (read at import)
+    set_operand_dtype(torch.bfloat16)  programmatic; affects modules' next forward (packed weights are re-made)
+"""
+import os
+
+import torch
+
+_NAMES = {"f16": torch.float16, "fp16": torch.float16, "half": torch.float16, "bf16": torch.bfloat16,
+          "bfloat16": torch.bfloat16}
+_operand = _NAMES[os.environ.get("IGGT_OPERAND_DTYPE", "f16").lower()]
+
+
+def operand_dtype() -> torch.dtype:
+    return _operand
+
+
+def set_operand_dtype(dt) -> None:
+    global _operand
+    if isinstance(dt, str):
+        dt = _NAMES[dt.lower()]
+    if dt not in (torch.float16, torch.bfloat16):
+        raise ValueError("operand dtype must be torch.float16 or torch.bfloat16")
+    _operand = dt
+
+
+_mean_comp = os.environ.get("IGGT_MEAN_COMP", "1") != "0"
+
+
+def mean_compensation() -> bool:
+    """Mean-input compensation of the weight rounding: fp16 operands only (see the module docstring)."""
+    return _mean_comp and _operand == torch.float16
+
+
+def set_mean_compensation(on: bool) -> None:
+    global _mean_comp
+    _mean_comp = bool(on)
+
+
+def operand_name() -> str:
+    return "f16" if _operand == torch.float16 else "bf16"

@@ -7,9 +7,15 @@
  * entry cites the reference operation (file:line under /root/reference) it replaces.
  *
  * Conventions: all pointers are device pointers unless stated; `ld*`/strides are in ELEMENTS;
- * bf16 tensors are passed as void*; every function returns 0 on success, a negative value for an
+ * 16-bit tensors are passed as void*; every function returns 0 on success, a negative value for an
  * argument-contract violation, or a positive hipError_t.  Functions only enqueue work on
  * `stream` (no host sync, no allocation) and are hipGraph-capturable.
+ *
+ * 16-bit operand format of the trunk kernels: the `_bf16` entry points take/produce bfloat16 (the
+ * reference's autocast GPU mode, demo.py:190-193), their `_f16` twins IEEE half -- same kernels, same MFMA
+ * rate (v_mfma_f32_32x32x16_{bf16,f16}), 11 instead of 8 significant bits per operand, stores saturating at
+ * +-65504.  fp16 is what the host model uses by default: it is what brings the outputs within 1e-3 of the
+ * fp32 CPU reference (oracle/precision_sim.py).
  */
 #ifndef IGGT_HIP_H
 #define IGGT_HIP_H
@@ -33,22 +39,32 @@ int iggt_gemm_bf16(const void* A, long lda, const void* W, long ldw, int M, int 
                    const float* bias, const float* gamma, const float* add_table,
                    void* out, long ldo, int out_is_f32, int accumulate, int act,
                    int rows_in, int rows_out, int row_off, void* stream);
+int iggt_gemm_f16(const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+                  const float* bias, const float* gamma, const float* add_table,
+                  void* out, long ldo, int out_is_f32, int accumulate, int act,
+                  int rows_in, int rows_out, int row_off, void* stream);
 
 /* softmax(scale * Q K^T) V, head dim 64, bf16 in/out, fp32 softmax; element (b,h,n,d) at
- * ptr + b*bs + n*rs + h*64 + d.  q_rows_per_wg: 0 (auto), 128 or 256.
+ * ptr + b*bs + n*rs + h*64 + d.  q_rows_per_wg: 0 (auto: the production kernel, tile chosen by shape); explicit
+ * codes 5128 / 5256 / 6128 / 6256 (production kernel, 128 / 256 query rows per workgroup, 64 / 128-key macro
+ * tiles) and, bf16 only, 128 / 256 / 512 (earlier kernel generations kept for A/B tests).
  * Replaces F.scaled_dot_product_attention (iggt/layers/attention.py:60-66). */
 int iggt_flash_attn_bf16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
                              int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
                              long v_bs, long v_rs, long o_bs, long o_rs, float scale,
                              int q_rows_per_wg, void* stream);
+int iggt_flash_attn_f16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
+                            int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
+                            long v_bs, long v_rs, long o_bs, long o_rs, float scale,
+                            int q_rows_per_wg, void* stream);
 
-/* LayerNorm over C in {256,512,1024,2048}; fp32 in ((x0|x1) concatenation when x1 != NULL), bf16 or
- * fp32 out; optional input-row remap in_row = (r / rows_in) * rows_stride + row_off + r % rows_in and
+/* LayerNorm over C in {256,512,1024,2048}; fp32 in ((x0|x1) concatenation when x1 != NULL); out_type 0 = bf16,
+ * 1 = fp32, 2 = fp16; optional input-row remap in_row = (r / rows_in) * rows_stride + row_off + r % rows_in and
  * output-row remap out_row = (r / rows_in) * orows_stride + orow_off + r % rows_in (orows_stride > 0).
  * Replaces nn.LayerNorm at iggt/layers/block.py:84,87, iggt/layers/vision_transformer.py:274 and
  * iggt/heads/dpt_head.py:232. */
 int iggt_layernorm_f32(const float* x0, long ld0, const float* x1, long ld1, const float* w,
-                       const float* b, void* out, long ldo, int out_is_f32, int rows, int C,
+                       const float* b, void* out, long ldo, int out_type, int rows, int C,
                        float eps, int rows_in, int rows_stride, int row_off, int orows_stride, int orow_off,
                        void* stream);
 
@@ -59,10 +75,23 @@ int iggt_qknorm_rope_bf16(const void* qkv, long ld_in, void* q_out, long ldq, vo
                           void* v_out, long ldv, const float* qw, const float* qb, const float* kw,
                           const float* kb, const float* cos_t, const float* sin_t, int T, int P,
                           int gw, int patch_start, float eps, void* stream);
+int iggt_qknorm_rope_f16(const void* qkv, long ld_in, void* q_out, long ldq, void* k_out, long ldk,
+                         void* v_out, long ldv, const float* qw, const float* qb, const float* kw,
+                         const float* kb, const float* cos_t, const float* sin_t, int T, int P,
+                         int gw, int patch_start, float eps, void* stream);
 
-/* ImageNet-normalise + im2row of 14x14 patches: img fp32 [S][3][H][W] -> bf16 [S*gh*gw][Kpad].
- * Replaces iggt/models/aggregator.py:206 and the unfold half of iggt/layers/patch_embed.py:75. */
-int iggt_im2row_patch14(const float* img, void* out, int S, int H, int W, int Kpad, void* stream);
+/* ImageNet-normalise + im2row of 14x14 patches: img fp32 [S][3][H][W] -> bf16 (out_f16 = 0) or fp16 (1)
+ * [S*gh*gw][Kpad].  Replaces iggt/models/aggregator.py:206 and the unfold half of iggt/layers/patch_embed.py:75. */
+int iggt_im2row_patch14(const float* img, void* out, int out_f16, int S, int H, int W, int Kpad, void* stream);
+
+/* Mean-input compensation of the 16-bit weight rounding (no counterpart in the reference, which is fp32 on the
+ * CPU path this repository is checked against; see iggt_official_amd/precision.py):
+ *   iggt_colmean_h16:      mu[k] = mean over rows 0, row_step, 2*row_step, ... of the 16-bit matrix x [rows][K]
+ *   iggt_bias_correct_h16: out[n] = (bias ? bias[n] : 0) + sum_k dw[n][k] * mu[k],  dw = W - round16(W) as 16-bit
+ * The corrected bias replaces the Linear's bias in the following iggt_gemm_* call (f16: 0 = bf16, 1 = fp16). */
+int iggt_colmean_h16(const void* x, long ld, int rows, int K, int row_step, int f16, float* mu, void* stream);
+int iggt_bias_correct_h16(const void* dw, long ldw, int N, int K, const float* mu, const float* bias, float* out,
+                          int f16, void* stream);
 
 /* dst[s][row_off + r][:] = (s == 0 && first_view_is_zero ? src0 : src1)[r][:]  (fp32).
  * Replaces iggt/layers/vision_transformer.py:222-234 and iggt/models/aggregator.py:230-234,338-361. */

@@ -1,13 +1,13 @@
 """End-to-end parity (GPU): IGGT forward on HIP kernels vs golden fixtures produced by the REFERENCE
 modules on CPU fp32 (oracle/make_golden.py), same seeded weights and inputs.
 
-Tolerances.  north_star asks for 1e-3 relative on the outputs.  The trunk computes, like the
-reference's own GPU mode (demo.py:193-195 autocast bf16), with bf16 GEMM/attention operands; the
-reference's bf16 mode itself deviates from its fp32 CPU mode by 7e-3 on tokens and 1e-3..1e-2 on
-outputs.  Gate: relative l2 error < 1e-2 on the four consumed
-token layers and on every output (and max-abs error < 3e-2 of the output range); the per-kernel tests
-(test_kernels_gpu.py, test_conv_gpu.py) hold each HIP kernel to its own rounding budget.  Every measured number is
-exported to gpurun_out/parity_report.json and discussed in DESIGN.md section 2."""
+Tolerances.  north_star asks for 1e-3 relative on the outputs against the reference's fp32 CPU path.
+  * default operand format, fp16 (iggt_official_amd/precision.py): gate = north_star's: relative l2 error < 1e-3 on
+    the four consumed token layers and on every output (max-abs error < 5e-3 of the output range);
+  * bf16 operands (the reference's own GPU mode, demo.py:193-195 autocast bf16, selectable): that mode itself
+    deviates from fp32 by 7e-3 on tokens and 1e-3..1e-2 on outputs: gate 1e-2 / 3e-2.
+The per-kernel tests (test_kernels_gpu.py, test_kernels_f16_gpu.py, test_conv_gpu.py) hold each HIP kernel to its
+own rounding budget.  Every measured number is exported to gpurun_out/parity_report.json."""
 import pytest
 import torch
 
@@ -20,9 +20,24 @@ TINY = ["tiny_s2_56_stress", "tiny_s3_84x56_stress", "tiny_s2_70_stress", "tiny_
 BIG = ["full_s2_518_stress", "demo_s3_336x504_stress"]
 
 
-def _run(case):
+@pytest.fixture(autouse=True)
+def _restore_operand_dtype():
+    from iggt_official_amd import precision
+
+    old, old_comp = precision.operand_dtype(), precision._mean_comp
+    yield
+    precision.set_operand_dtype(old)
+    precision.set_mean_compensation(old_comp)
+
+
+GATES = {"f16": (1e-3, 5e-3), "bf16": (1e-2, 3e-2)}   # (relative l2, max-abs / range)
+
+
+def _run(case, operands="f16"):
+    from iggt_official_amd import precision
     from oracle import weights
 
+    precision.set_operand_dtype(operands)
     g = load_golden(case)
     m = g["meta"]
     model = build_gpu_model(m["mode"], m["weight_seed"])
@@ -35,9 +50,10 @@ def _run(case):
     return g, m, pred, cap["tokens"]
 
 
-@pytest.mark.parametrize("case", TINY + BIG)
-def test_forward_matches_reference(case):
-    g, m, pred, tokens = _run(case)
+@pytest.mark.parametrize("case,operands", [(c, "f16") for c in TINY + BIG]
+                         + [("tiny_s2_56_stress", "bf16"), ("full_s2_518_stress", "bf16")])
+def test_forward_matches_reference(case, operands):
+    g, m, pred, tokens = _run(case, operands)
     ss, ts = m["spatial_stride"], m["token_stride"]
     res = {}
     for li in (4, 11, 17, 23):
@@ -52,7 +68,7 @@ def test_forward_matches_reference(case):
         res["part_feat"] = errors(pred["part_feat"][:, :, :, ::ss, ::ss], g["part_feat"])
     else:
         assert "part_feat" not in pred
-    report(f"e2e/{case}", {k: dict(max=v[0], l2=v[1], l2_centered=v[2]) for k, v in res.items()})
+    report(f"e2e/{case}" + ("" if operands == "f16" else "/bf16"), {k: dict(max=v[0], l2=v[1], l2_centered=v[2]) for k, v in res.items()})
     for k, v in pred.items():
         if torch.is_tensor(v):
             assert torch.isfinite(v).all(), k
@@ -62,13 +78,13 @@ def test_forward_matches_reference(case):
     assert pred["world_points"].shape == (1, S, H, W, 3) and pred["world_points_conf"].shape == (1, S, H, W)
     assert len(pred["pose_enc"]) == 4 and pred["pose_enc"][-1].shape == (1, S, 9)
     assert all(v.dtype == torch.float32 for v in pred.values() if torch.is_tensor(v))
-    # gates: bf16-operand trunk vs fp32 CPU reference (see module docstring)
-    # measured on MI355X: tokens 6.2e-3..7.2e-3, outputs 6e-4..7.1e-3 (profiles/r01_parity_report.json)
+    # gates vs the fp32 CPU reference (see module docstring; measured values in profiles/r01_parity_report.json)
+    g_l2, g_max = GATES[operands]
     for li in (4, 11, 17, 23):
-        assert res[f"tokens_{li}"][1] < 1e-2, (li, res[f"tokens_{li}"])
+        assert res[f"tokens_{li}"][1] < g_l2, (li, res[f"tokens_{li}"])
     for k in ("depth", "depth_conf", "world_points", "world_points_conf", "part_feat", "pose_enc"):
         if k in res:
-            assert res[k][1] < 1e-2 and res[k][0] < 3e-2, (k, res[k])
+            assert res[k][1] < g_l2 and res[k][0] < g_max, (k, res[k])
 
 
 def test_dino_backbone_tokens():
@@ -83,19 +99,24 @@ def test_dino_backbone_tokens():
         out = model.aggregator.patch_embed.forward_features(images)["x_norm_patchtokens"]
         e = errors(out[:, ::m["token_stride"]], g["dino"])
         report(f"dino/{case}", dict(max=e[0], l2=e[1]))
-        assert e[1] < 1e-2, e
+        assert e[1] < 1e-3, e   # fp16 operands (default)
 
 
 def test_chunked_heads_equal_unchunked():
-    """frames_chunk_size must not change the result."""
+    """frames_chunk_size must not change the result: exactly the same arithmetic per frame
+    with the mean-input compensation off; with it on (default) the token projection of each chunk is compensated with
+    that chunk's own input mean, which moves the result by a few 1e-5 relative -- far inside the parity budget."""
+    from iggt_official_amd import precision
     from oracle import weights
 
     model = build_gpu_model("stress", 0)
     images = weights.make_images(5, 56, 56, seed=9, device="cuda")[None]
     tokens, psi = model.aggregator(images)
-    a = model.depth_head(tokens, images=images, patch_start_idx=psi, frames_chunk_size=None)
-    b = model.depth_head(tokens, images=images, patch_start_idx=psi, frames_chunk_size=2)
-    assert torch.allclose(a[0], b[0], rtol=1e-5, atol=1e-6) and torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-6)
+    for comp, rtol, atol in ((False, 1e-5, 1e-6), (True, 5e-4, 5e-5)):
+        precision.set_mean_compensation(comp)
+        a = model.depth_head(tokens, images=images, patch_start_idx=psi, frames_chunk_size=None)
+        b = model.depth_head(tokens, images=images, patch_start_idx=psi, frames_chunk_size=2)
+        assert torch.allclose(a[0], b[0], rtol=rtol, atol=atol) and torch.allclose(a[1], b[1], rtol=rtol, atol=atol)
 
 
 def test_no_cpu_fallback():

@@ -1,0 +1,215 @@
+"""fp16-operand twins of the trunk kernels (include/iggt_hip.h `_f16` entry points), the default operand format of
+the host model (iggt_official_amd/precision.py).  Same structure as test_kernels_gpu.py: fp64 reference on the SAME
+fp16-rounded operands; admissible differences are accumulation order and the documented internal roundings, now at
+fp16's 2^-11.  Tolerances are stated per test (8x tighter than the bf16 ones where a 16-bit rounding is involved)."""
+import pytest
+import torch
+
+from conftest import report
+from test_kernels_gpu import _attn_ref, _rand, _relerr, _rope_ref
+
+pytestmark = pytest.mark.gpu
+F16 = torch.float16
+
+
+@pytest.fixture(scope="module")
+def C():
+    from iggt_official_amd import _C
+
+    _C.load()
+    return _C
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1374, 3072, 1024), (77, 1024, 4096), (1000, 96, 640), (33, 9, 128)])
+def test_gemm_f16_plain_f32_out(C, M, N, K):
+    a = _rand((M, K), 1, dtype=F16)
+    w = _rand((N, K), 2, K ** -0.5, dtype=F16)
+    bias = _rand((N,), 3)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    C.gemm_h16(a, w, out, bias=bias)
+    ref = a.double() @ w.double().t() + bias.double()
+    mx, l2 = _relerr(out, ref)
+    report(f"gemm_f16_f32out_{M}x{N}x{K}", dict(max=mx, l2=l2))
+    assert mx < 2e-5, (mx, l2)  # fp32 accumulation of exact fp16 products
+
+
+def test_gemm_f16_mixed_operands_rejected(C):
+    a = _rand((128, 64), 1, dtype=F16)
+    w = _rand((128, 64), 2, dtype=torch.bfloat16)
+    with pytest.raises(C.HipExtensionError):
+        C.gemm_h16(a, w, torch.empty(128, 128, device="cuda"))
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(5000, 4096, 1024, "gelu"), (4122, 1024, 4096, "acc"), (2738, 1024, 640, "remap"),
+                                        (43968, 3072, 1024, "plain"), (300, 256, 128, "gelu")])
+def test_gemm_f16_epilogues(C, M, N, K, mode):
+    """Both GEMM kernels (256x256 LDS-DMA ping-pong for the large shapes, 128x128 for the small one)."""
+    a = _rand((M, K), 70, dtype=F16)
+    w = _rand((N, K), 71, K ** -0.5, dtype=F16)
+    bias, gamma = _rand((N,), 72, 0.1), _rand((N,), 73)
+    base = (a.double() @ w.double().t() + bias.double()) if M < 20000 else None
+    if mode == "gelu":
+        out = torch.empty(M, N, dtype=F16, device="cuda")
+        C.gemm_h16(a, w, out, bias=bias, act=1)
+        mx, l2 = _relerr(out, torch.nn.functional.gelu(base))
+        report(f"gemm_f16_gelu_{M}", dict(max=mx, l2=l2))
+        assert mx < 8e-4 and l2 < 4e-4  # one fp16 rounding of the output (2^-11 relative) + A&S erfc (1.5e-7)
+    elif mode == "acc":
+        x = _rand((M, N), 74)
+        ref = x.double() + gamma.double() * base
+        C.gemm_h16(a, w, x, bias=bias, gamma=gamma, accumulate=True)
+        assert _relerr(x, ref)[0] < 2e-5
+    elif mode == "remap":
+        g2 = 1369
+        S = M // g2
+        table = _rand((g2, N), 75)
+        out = torch.full((S * (g2 + 5), N), -7.0, device="cuda")
+        C.gemm_h16(a, w, out, bias=bias, add_table=table, rows_in=g2, rows_out=g2 + 5, row_off=5)
+        o = out.view(S, g2 + 5, N)
+        assert torch.all(o[:, :5] == -7.0)
+        assert _relerr(o[:, 5:], base.view(S, g2, N) + table.double())[0] < 2e-5
+    else:
+        out = torch.full((M, N), float("nan"), device="cuda")
+        C.gemm_h16(a, w, out, bias=bias)
+        rows = torch.arange(0, M, 97, device="cuda")
+        base_s = a[rows].double() @ w.double().t() + bias.double()
+        assert not torch.isnan(out).any() and _relerr(out[rows], base_s)[0] < 2e-5
+
+
+def test_gemm_f16_store_saturates(C):
+    """fp16 outputs beyond the finite range are clamped to +-65504 instead of becoming inf."""
+    M, N, K = 256, 256, 128
+    a = torch.full((M, K), 60.0, dtype=F16, device="cuda")
+    w = torch.full((N, K), 60.0, dtype=F16, device="cuda")
+    w[N // 2:] = -60.0
+    out = torch.empty(M, N, dtype=F16, device="cuda")
+    C.gemm_h16(a, w, out)   # 128 * 3600 = 460800 > 65504
+    assert torch.all(out[:, : N // 2] == 65504.0) and torch.all(out[:, N // 2:] == -65504.0)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,tile", [(2, 16, 1374, 1374, 0), (1, 16, 4122, 4122, 0), (3, 4, 21, 21, 0),
+                                            (1, 16, 4122, 4122, 5256), (1, 16, 2748, 5496, 6256),
+                                            (2, 3, 1374, 1374, 6128), (1, 2, 300, 777, 6256), (1, 2, 300, 777, 5128),
+                                            (1, 1, 40, 64, 6256), (1, 2, 1000, 65, 6256), (1, 2, 500, 129, 6128)])
+def test_flash_attn_f16(C, B, H, Nq, Nk, tile):
+    Cdim = H * 64
+    N = max(Nq, Nk)
+    qkv = _rand((B * N, 3 * Cdim), 20 + Nq, 1.0, F16)
+    o = torch.full((B * Nq, Cdim), float("nan"), dtype=F16, device="cuda")
+    C.flash_attn_d64(qkv, qkv[:, Cdim:], qkv[:, 2 * Cdim:], o, B, H, Nq, Nk,
+                     N * 3 * Cdim, 3 * Cdim, N * 3 * Cdim, 3 * Cdim, N * 3 * Cdim, 3 * Cdim, Nq * Cdim, Cdim,
+                     0.125, tile)
+    x = qkv.view(B, N, 3, H, 64)
+    q, k, v = x[:, :Nq, 0].transpose(1, 2), x[:, :Nk, 1].transpose(1, 2), x[:, :Nk, 2].transpose(1, 2)
+    ref = _attn_ref(q, k, v, 0.125).transpose(1, 2).reshape(B * Nq, Cdim)
+    assert not torch.isnan(o.float()).any()
+    mx, l2 = _relerr(o, ref)
+    report(f"attn_f16_B{B}_H{H}_{Nq}x{Nk}_t{tile}", dict(max=mx, l2=l2))
+    # P and O are rounded to fp16 (2^-11 each): 8x below the bf16 kernel's 1.5e-2 / 4e-3
+    assert mx < 2e-3 and l2 < 5e-4, (mx, l2)
+
+
+def test_flash_attn_f16_peaked_and_wide_range(C):
+    """(a) a dominant key in a late tile (online-softmax rescale); (b) one key 14 nats above a large diffuse crowd:
+    the crowd's numerators sit near fp16's normal limit and still carry ~40 % of the mass -- the 2^P_SHIFT scaling of
+    the numerators (csrc/attention_common.h) keeps them out of the subnormal range."""
+    H, N = 2, 4000
+    Cdim = H * 64
+    qkv = _rand((N, 3 * Cdim), 33, 0.5, F16)
+    x = qkv.view(N, 3, H, 64)
+    x[700, 1] = x[123, 0] * 8.0
+    x[901, 1] = x[5, 0] * 6.0
+    # (b): query 77 of head 0: all keys orthogonal-ish (score ~0) except key 3000 with score ~ +8 nats
+    x[77, 0, 0] = 0
+    x[77, 0, 0, 0] = 8.0
+    x[:, 1, 0, 0] = 0
+    x[3000, 1, 0, 0] = 8.0            # score 64 * 0.125 = 8 nats above the crowd (crowd mass 3999 vs e^8 = 2981)
+    o = torch.empty(N, Cdim, dtype=F16, device="cuda")
+    C.flash_attn_d64(qkv, qkv[:, Cdim:], qkv[:, 2 * Cdim:], o, 1, H, N, N, 0, 3 * Cdim, 0, 3 * Cdim, 0, 3 * Cdim,
+                     0, Cdim, 0.125, 0)
+    q, k, v = x[:, 0].transpose(0, 1), x[:, 1].transpose(0, 1), x[:, 2].transpose(0, 1)
+    ref = _attn_ref(q, k, v, 0.125).transpose(0, 1).reshape(N, Cdim)
+    mx, l2 = _relerr(o, ref)
+    assert mx < 2e-3 and l2 < 5e-4, (mx, l2)
+    row = _relerr(o[77, :64], ref[77, :64])
+    assert row[1] < 1e-3, row
+
+
+def test_flash_attn_f16_legacy_tiles_rejected(C):
+    qkv = _rand((64, 3 * 64), 1, 1.0, F16)
+    o = torch.empty(64, 64, dtype=F16, device="cuda")
+    with pytest.raises(C.HipExtensionError):
+        C.flash_attn_d64(qkv, qkv[:, 64:], qkv[:, 128:], o, 1, 1, 64, 64, 0, 192, 0, 192, 0, 192, 0, 64, 0.125, 128)
+
+
+def test_layernorm_f16_out(C):
+    rows, Cdim = 1003, 1024
+    x = _rand((rows, Cdim), 40, 3.0) + 0.7
+    w, b = _rand((Cdim,), 41) * 0.1 + 1, _rand((Cdim,), 42, 0.1)
+    big = torch.empty(rows, Cdim + 64, dtype=F16, device="cuda")
+    out = big[:, :Cdim]     # padded row stride (layers/blocks.py ROW_PAD)
+    C.layernorm(x, w, b, out, 1e-5)
+    ref = torch.nn.functional.layer_norm(x.double(), (Cdim,), w.double(), b.double(), 1e-5)
+    mx, l2 = _relerr(out, ref)
+    assert mx < 7e-4 and l2 < 4e-4, (mx, l2)
+
+
+def test_qknorm_rope_f16(C):
+    from iggt_official_amd.layers.rope import RotaryPositionEmbedding2D
+
+    S, gh, gw, psi = 2, 5, 7, 5
+    P = psi + gh * gw
+    T = S * P
+    qkv = _rand((T, 3072), 50, 1.5, F16)
+    orig = qkv.clone()
+    qw, qb, kw, kb = (_rand((64,), 51) * 0.1 + 1, _rand((64,), 52, 0.1), _rand((64,), 53) * 0.1 + 1,
+                      _rand((64,), 54, 0.1))
+    cos, sin = RotaryPositionEmbedding2D(100).tables(64, max(gh, gw), torch.device("cuda"))
+    vcopy = torch.empty(T, 1024, dtype=F16, device="cuda")
+    C.qknorm_rope(qkv, qkv, qkv[:, 1024:], vcopy, qw, qb, kw, kb, cos, sin, T, P, gw, psi, 1e-5)
+    pos = torch.zeros(P, 2, dtype=torch.long)
+    ys, xs = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+    pos[psi:, 0], pos[psi:, 1] = ys.flatten() + 1, xs.flatten() + 1
+    pos = pos.repeat(S, 1)
+    for idx, (w_, b_) in enumerate([(qw, qb), (kw, kb)]):
+        t = orig[:, idx * 1024:(idx + 1) * 1024].double().cpu().view(T, 16, 64)
+        t = torch.nn.functional.layer_norm(t, (64,), w_.double().cpu(), b_.double().cpu(), 1e-5)
+        ref = _rope_ref(t, pos).reshape(T, 1024)
+        got = qkv[:, idx * 1024:(idx + 1) * 1024].double().cpu()
+        mx, l2 = _relerr(got, ref)
+        assert mx < 8e-4 and l2 < 4e-4, (idx, mx, l2)  # one fp16 rounding of the result
+    assert torch.equal(qkv[:, 2048:], orig[:, 2048:]) and torch.equal(vcopy, orig[:, 2048:])
+
+
+def test_im2row_f16(C):
+    S, H, W = 2, 28, 42
+    img = torch.rand(S, 3, H, W, generator=torch.Generator().manual_seed(60)).cuda()
+    gh, gw = H // 14, W // 14
+    out = torch.empty(S * gh * gw, 640, dtype=F16, device="cuda")
+    C.im2row_patch14(img, out, S, H, W, 640)
+    mean = torch.tensor([0.485, 0.456, 0.406], device="cuda").view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], device="cuda").view(1, 3, 1, 1)
+    ref = torch.nn.functional.unfold((img - mean) / std, 14, stride=14).transpose(1, 2).reshape(S * gh * gw, 588)
+    assert torch.all(out[:, 588:] == 0)
+    assert (out[:, :588].float() - ref).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [F16, torch.bfloat16])
+@pytest.mark.parametrize("rows,K,step", [(43, 1024, 1), (5000, 4096, 2), (1369, 640, 3), (7, 2048, 16)])
+def test_colmean_and_bias_correct(C, dtype, rows, K, step):
+    """Mean-input compensation kernels: mu = column mean over a row sample; out = bias + dW mu."""
+    big = _rand((rows, K + 64), 90, 2.0, dtype) + 0.5
+    x = big[:, :K]                                    # padded row stride
+    mu = torch.full((K,), float("nan"), device="cuda")
+    C.colmean(x, mu, step)
+    ref_mu = x[::step].double().mean(0)
+    assert _relerr(mu, ref_mu)[0] < 1e-5
+    N = 384
+    dw = _rand((N, K), 91, 1e-4, dtype)
+    bias = _rand((N,), 92)
+    out = torch.empty(N, device="cuda")
+    C.bias_correct(dw, mu, bias, out)
+    ref = bias.double() + dw.double() @ mu.double()
+    assert float((out.double() - ref).abs().max()) < 1e-6
+    C.bias_correct(dw, mu, None, out)
+    assert float((out.double() - dw.double() @ mu.double()).abs().max()) < 1e-6
