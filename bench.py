@@ -6,8 +6,9 @@
 
 Workload (BASELINE.json configs[2] / [3]): 32 synthetic views @ 518x518, end-to-end forward =
 DINOv2 backbone + 24 x (frame, global) blocks + camera head + depth head + point head, random-init
-weights of the reference architecture (no checkpoint reachable), bf16 MFMA operands with fp32
-accumulation = the reference's own GPU precision (demo.py:193-195).  518 is not a multiple of 28, where
+weights of the reference architecture (no checkpoint reachable), 16-bit MFMA operands with fp32 accumulation:
+fp16 by default -- the format whose outputs stay within 1e-3 of the reference's fp32 CPU path (tests/test_e2e_gpu.py);
+IGGT_OPERAND_DTYPE=bf16 selects the reference's own GPU precision (demo.py:193-195), same MFMA rate.  518 is not a multiple of 28, where
 the reference's part head raises, so the step produces the geometry outputs --
 exactly what the reference can produce at this size.  One "step" = one full forward of all views.
 Views are sharded over ranks ("strong" scaling: 32 views total for every N); the only data-path
@@ -16,7 +17,7 @@ collective is the K/V all-gather in front of each global attention (iggt_officia
 Prints ONE JSON line (rank 0) with value = total views / second, plus
   "roofline": global-attention flash kernel, algorithmic FLOPs (4*Nq*Nk*C per launch) / mean launch
               duration measured with HIP events on the launch stream inside the timed region, against
-              the 2.5 PFLOP/s dense bf16 MFMA peak;
+              the 2.5 PFLOP/s dense 16-bit (bf16 = fp16) MFMA peak;
   "cpu_baseline": the CPU restatement of the reference (oracle/restate.py, kind "port") timed on this
               box's host cores on a bounded sample (2 views @ 518x518), rank 0 / N=1 only.
 """
@@ -34,7 +35,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
 # HBM-side bytes per global-attention launch at 32 views x 518^2 on one GPU, from rocprofv3 PMC passes
 # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE): profiles/r01_attn_hbm_pmc.txt.  Not measurable live.
 PMC_TRAFFIC_BYTES = {(32, 518, 1): 1.17e9}
@@ -115,7 +116,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from iggt.models.vggt import IGGT
-    from iggt_official_amd import _C, profiling
+    from iggt_official_amd import _C, precision, profiling
     from iggt_official_amd.dist import ViewShard, view_partition
 
     _C.load()
@@ -174,12 +175,12 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": precision.operand_name(),
             "data": "synthetic",
             "config": {"workload": f"{S} views @ {H}x{H}, IGGT forward (DINOv2 + 24x(frame,global) + camera/depth/"
                                    "point heads), random-init weights, views sharded " + f"{S // world}/GPU",
                        "views": S, "image_size": H, "tokens_per_view": P, "parallelism": f"view-shard x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "flash_attn_d64_v3_kernel<2,2> (global attention)",
+            "roofline": {"bound": "mfma", "kernel": f"flash_attn_d64_v3_kernel<2,2,{precision.operand_name()}> (global attention)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": PMC_TRAFFIC_BYTES.get((S, H, world)),

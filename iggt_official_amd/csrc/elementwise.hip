@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void write_special_tokens_kernel(const Special
 // small matrix-vector product, folded into the GEMM's bias:  b' = b + dW mu.
 //
 // colmean: mu[k] = mean over rows r = 0, step, 2*step, ... of x[r][k].  One block per 64 columns; thread -> (8-column
-// slot, one of 32 row lanes); 16-byte loads; LDS tree over the row lanes.
+// slot, one of 128 row lanes); 16-byte loads, 4 in flight; fixed-order LDS reduction over the row lanes.
 struct ColMeanParams {
     const bf16_t* x;
     long ld;
@@ -248,14 +248,18 @@ struct ColMeanParams {
 };
 
 template <int FMT>
-__global__ __launch_bounds__(256) void colmean_kernel(const ColMeanParams p) {
-    __shared__ float red[32][65];
+__global__ __launch_bounds__(1024) void colmean_kernel(const ColMeanParams p) {
+    constexpr int RL = 128;  // row lanes: 1024 threads = 8 column slots x 128 row lanes
+    __shared__ float red[RL][65];
     const int slot = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int col = blockIdx.x * 64 + slot * 8;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (col < p.K) {
-        for (int i = rl; i < p.nsamp; i += 32) {
-            const u32x4 raw = *reinterpret_cast<const u32x4*>(p.x + (long)i * p.step * p.ld + col);
+        const bf16_t* src = p.x + col;
+        const long rstride = (long)p.step * p.ld;
+#pragma unroll 4
+        for (int i = rl; i < p.nsamp; i += RL) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(src + i * rstride);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[2 * e] += h2_lo<FMT>(raw[e]);
@@ -267,11 +271,16 @@ __global__ __launch_bounds__(256) void colmean_kernel(const ColMeanParams p) {
     for (int e = 0; e < 8; ++e) red[rl][slot * 8 + e] = acc[e];
     __syncthreads();
     if (threadIdx.x < 64) {
-        float sum = 0.f;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // fixed summation order: deterministic
 #pragma unroll 8
-        for (int r = 0; r < 32; ++r) sum += red[r][threadIdx.x];
+        for (int r = 0; r < RL; r += 4) {
+            s0 += red[r][threadIdx.x];
+            s1 += red[r + 1][threadIdx.x];
+            s2 += red[r + 2][threadIdx.x];
+            s3 += red[r + 3][threadIdx.x];
+        }
         const int c = blockIdx.x * 64 + threadIdx.x;
-        if (c < p.K) p.mu[c] = sum / (float)p.nsamp;
+        if (c < p.K) p.mu[c] = ((s0 + s1) + (s2 + s3)) / (float)p.nsamp;
     }
 }
 
@@ -401,7 +410,7 @@ extern "C" int iggt_colmean_h16(const void* x, long ld, int rows, int K, int row
     p.x = (const bf16_t*)x; p.ld = ld; p.rows = rows; p.K = K; p.step = row_step;
     p.nsamp = (rows + row_step - 1) / row_step;
     p.mu = mu;
-    const dim3 grid((K + 63) / 64), block(256);
+    const dim3 grid((K + 63) / 64), block(1024);
     if (f16) hipLaunchKernelGGL(colmean_kernel<FMT_F16>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(colmean_kernel<FMT_BF16>, grid, block, 0, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();

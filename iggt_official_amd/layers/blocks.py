@@ -106,7 +106,7 @@ def _h16_residual(lin: nn.Linear, dt: torch.dtype):
     return (w - w.to(dt).float()).to(dt).contiguous()
 
 
-MEAN_SAMPLE_ROWS = 2048  # the column mean is taken over ~this many evenly spaced rows (sampling error 1/45 sigma)
+MEAN_SAMPLE_ROWS = 1024  # the column mean is taken over ~this many evenly spaced rows (sampling error sigma / 32)
 
 
 def compensated_bias(ws: "Workspace", a: torch.Tensor, dw: Optional[torch.Tensor], bias: Optional[torch.Tensor]):

@@ -12,7 +12,7 @@ Of the eight rounding sites of a block (oracle/precision_sim.py --ablate) the WE
 rounding is the same for every token, so it does not average out (tokens 8.6e-4 -> 3.8e-4 with exact weights; the
 seven activation sites together matter less than the weights of any one GEMM).  Almost all of that is the response
 to the MEAN input vector: x W^T = x Wh^T + mu dW^T + (x - mu) dW^T with Wh = round16(W), dW = W - Wh, mu = mean over
-tokens of the GEMM input.  "Mean-input compensation" restores the middle term exactly: a column mean over ~2048 evenly
+tokens of the GEMM input.  "Mean-input compensation" restores the middle term exactly: a column mean over ~1024 evenly
 spaced rows of the input and one small matrix-vector product give b' = b + dW mu, which replaces the bias of the GEMM
 (csrc/elementwise.hip colmean / bias_correct; layers/blocks.py compensated_bias).  Simulated token error 8.6e-4 ->
 4.3e-4 for two tiny kernels per GEMM (~1.5 % of the step).  On with fp16 operands, off in bf16 mode, which keeps the
