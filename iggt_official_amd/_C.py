@@ -12,7 +12,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -35,10 +35,10 @@ _SIGNATURES = {
                            _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p],
     "iggt_qknorm_rope_bf16": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long,
                               _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                              _c_int, _c_int, _c_int, _c_int, _c_float, _c_void_p],
+                              _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_long, _c_long, _c_void_p],
     "iggt_qknorm_rope_f16": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long,
                              _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                             _c_int, _c_int, _c_int, _c_int, _c_float, _c_void_p],
+                             _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_long, _c_long, _c_void_p],
     "iggt_im2row_patch14": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p],
     "iggt_colmean_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "iggt_bias_correct_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
@@ -171,7 +171,8 @@ def layernorm(x0, w, b, out, eps, *, x1=None, rows=None, rows_in=0, rows_stride=
     return out
 
 
-def qknorm_rope(qkv, q_out, k_out, v_out, qw, qb, kw, kb, cos_t, sin_t, T, P, gw, patch_start, eps):
+def qknorm_rope(qkv, q_out, k_out, v_out, qw, qb, kw, kb, cos_t, sin_t, T, P, gw, patch_start, eps,
+                heads_per_group=0, k_group_stride=0, v_group_stride=0):
     _dev(qkv, q_out, k_out, v_out, qw, cos_t)
     sfx = _h16(qkv, q_out, k_out) if v_out is None else _h16(qkv, q_out, k_out, v_out)
     assert qkv.shape[-1] == 3072
@@ -179,7 +180,8 @@ def qknorm_rope(qkv, q_out, k_out, v_out, qw, qb, kw, kb, cos_t, sin_t, T, P, gw
     rc = fn(qkv.data_ptr(), qkv.stride(0), q_out.data_ptr(), q_out.stride(0),
             k_out.data_ptr(), k_out.stride(0), _ptr(v_out), 0 if v_out is None else v_out.stride(0),
             qw.data_ptr(), qb.data_ptr(), kw.data_ptr(), kb.data_ptr(),
-            cos_t.data_ptr(), sin_t.data_ptr(), T, P, gw, patch_start, float(eps), _stream())
+            cos_t.data_ptr(), sin_t.data_ptr(), T, P, gw, patch_start, float(eps),
+            heads_per_group, k_group_stride, v_group_stride, _stream())
     _check(rc, "iggt_qknorm_rope_" + sfx)
 
 

@@ -108,6 +108,10 @@ struct QkParams {
     int T, P, gw, patch_start;
     float eps;
     int C;  // 1024
+    // head-group layout of the k / v outputs (multi-GPU K/V gather pipelined over head groups, dist.py): head h
+    // goes to  out + (h / hg) * group_stride + t * ld + (h % hg) * 64.   hg = 16, stride 0: flat [T][C] rows.
+    int hg;
+    long kgs, vgs;
 };
 
 template <int FMT>
@@ -159,12 +163,14 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = pack_h2<FMT>(y[2 * e], y[2 * e + 1]);
-    bf16_t* dst = which ? (p.k_out + (long)t * p.ldk) : (p.q_out + (long)t * p.ldq);
-    *reinterpret_cast<u32x4*>(dst + head * 64 + j * 8) = o;
+    const int hgrp = head / p.hg, hin = head - hgrp * p.hg;
+    bf16_t* dst = which ? (p.k_out + hgrp * p.kgs + (long)t * p.ldk + hin * 64) : (p.q_out + (long)t * p.ldq + head * 64);
+    *reinterpret_cast<u32x4*>(dst + j * 8) = o;
 
-    if (p.v_out != nullptr && tid < 128) {  // copy v: 1024 bf16 = 128 x 16 B
+    if (p.v_out != nullptr && tid < 128) {  // copy v: 1024 x 16 bit = 128 x 16 B; thread -> (head tid/8, slice tid%8)
         const u32x4 vv = *reinterpret_cast<const u32x4*>(p.qkv + (long)t * p.ld_in + 2 * p.C + tid * 8);
-        *reinterpret_cast<u32x4*>(p.v_out + (long)t * p.ldv + tid * 8) = vv;
+        const int vh = tid >> 3, vg = vh / p.hg;
+        *reinterpret_cast<u32x4*>(p.v_out + vg * p.vgs + (long)t * p.ldv + (vh - vg * p.hg) * 64 + (tid & 7) * 8) = vv;
     }
 }
 
@@ -343,7 +349,7 @@ extern "C" int iggt_layernorm_f32(const float* x0, long ld0, const float* x1, lo
 static int qknorm_rope_h16(int fmt, const void* qkv, long ld_in, void* q_out, long ldq, void* k_out, long ldk,
                            void* v_out, long ldv, const float* qw, const float* qb, const float* kw, const float* kb,
                            const float* cos_t, const float* sin_t, int T, int P, int gw, int patch_start, float eps,
-                           void* stream) {
+                           int heads_per_group, long k_group_stride, long v_group_stride, void* stream) {
     if (T <= 0 || P <= 0) return -1;
     if ((ld_in % 8) || (ldq % 8) || (ldk % 8) || (v_out && (ldv % 8))) return -2;
     QkParams p;
@@ -352,6 +358,12 @@ static int qknorm_rope_h16(int fmt, const void* qkv, long ld_in, void* q_out, lo
     p.v_out = (bf16_t*)v_out; p.ldv = ldv;
     p.qw = qw; p.qb = qb; p.kw = kw; p.kb = kb; p.cos_t = cos_t; p.sin_t = sin_t;
     p.T = T; p.P = P; p.gw = gw; p.patch_start = patch_start; p.eps = eps; p.C = 1024;
+    if (heads_per_group <= 0 || heads_per_group >= 16) {
+        p.hg = 16; p.kgs = 0; p.vgs = 0;
+    } else {
+        if ((16 % heads_per_group) || (k_group_stride % 8) || (v_group_stride % 8)) return -3;
+        p.hg = heads_per_group; p.kgs = k_group_stride; p.vgs = v_group_stride;
+    }
     if (fmt == FMT_F16) hipLaunchKernelGGL(qknorm_rope_kernel<FMT_F16>, dim3(T), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(qknorm_rope_kernel<FMT_BF16>, dim3(T), dim3(256), 0, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
@@ -361,17 +373,19 @@ static int qknorm_rope_h16(int fmt, const void* qkv, long ld_in, void* q_out, lo
 extern "C" int iggt_qknorm_rope_bf16(const void* qkv, long ld_in, void* q_out, long ldq, void* k_out, long ldk,
                                      void* v_out, long ldv, const float* qw, const float* qb, const float* kw,
                                      const float* kb, const float* cos_t, const float* sin_t, int T, int P,
-                                     int gw, int patch_start, float eps, void* stream) {
+                                     int gw, int patch_start, float eps, int heads_per_group, long k_group_stride,
+                                     long v_group_stride, void* stream) {
     return qknorm_rope_h16(FMT_BF16, qkv, ld_in, q_out, ldq, k_out, ldk, v_out, ldv, qw, qb, kw, kb, cos_t, sin_t, T, P,
-                           gw, patch_start, eps, stream);
+                           gw, patch_start, eps, heads_per_group, k_group_stride, v_group_stride, stream);
 }
 
 extern "C" int iggt_qknorm_rope_f16(const void* qkv, long ld_in, void* q_out, long ldq, void* k_out, long ldk,
                                     void* v_out, long ldv, const float* qw, const float* qb, const float* kw,
                                     const float* kb, const float* cos_t, const float* sin_t, int T, int P,
-                                    int gw, int patch_start, float eps, void* stream) {
+                                    int gw, int patch_start, float eps, int heads_per_group, long k_group_stride,
+                                    long v_group_stride, void* stream) {
     return qknorm_rope_h16(FMT_F16, qkv, ld_in, q_out, ldq, k_out, ldk, v_out, ldv, qw, qb, kw, kb, cos_t, sin_t, T, P,
-                           gw, patch_start, eps, stream);
+                           gw, patch_start, eps, heads_per_group, k_group_stride, v_group_stride, stream);
 }
 
 extern "C" int iggt_im2row_patch14(const float* img, void* out, int out_f16, int S, int H, int W, int Kpad,

@@ -11,12 +11,20 @@ K and V, and (b) the camera head, which attends across the S camera tokens.
   buffer directly consumable by the attention kernel: keys of rank r are rows [r*T_l, (r+1)*T_l));
   softmax is permutation-invariant over keys so no re-ordering is needed.  32 views x 518^2 on 8
   GPUs: 22.5 MB per rank per block; on the xGMI full mesh RCCL moves it as direct peer writes.
+* optional (kv_groups = G > 1, IGGT_KV_GROUPS): the gather PIPELINED over head groups: q/k-norm+RoPE writes K and V
+  in head-group layout [G][T_local][2 * (16/G) * 64] (csrc/elementwise.hip), the G all-gathers are issued back to
+  back as async collectives, and the attention of head group g (its own launch, on a side stream) starts as soon as
+  collective g has landed while g+1.. are still on the wire -- heads are independent, so no partial-softmax merge
+  is needed and every collective still uses all xGMI links.  Correct (tests/test_shard_gpu.py, test_dist_gloo.py) but
+  OFF by default: on one MI355X the four concurrent 4-head launches of an 8-GPU rank take 1.84 ms against 1.26 ms
+  for the single 16-head launch (probes/attn_groups.py) -- more than the ~0.45 ms of transport they can hide.
 * the S camera tokens ([S, 2048] fp32, 256 KB at S=32) are all-gathered once for the camera head.
 
 Works with any initialised process group: "nccl" (= RCCL) on GPUs, "gloo" on CPU for the
 host-logic tests (tests/test_dist_gloo.py).
 """
-from typing import Optional, Tuple
+import os
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -31,13 +39,19 @@ def view_partition(S: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 class ViewShard:
-    def __init__(self, group: Optional["dist.ProcessGroup"] = None):
+    def __init__(self, group: Optional["dist.ProcessGroup"] = None, kv_groups: Optional[int] = None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self._bufs = {}
+        g = int(os.environ.get("IGGT_KV_GROUPS", "1")) if kv_groups is None else int(kv_groups)
+        if g not in (1, 2, 4, 8, 16):
+            raise ValueError("kv_groups must divide the 16 heads")
+        self.kv_groups = g if self.world > 1 else 1
+        self._streams: List = []
+        self._events: List = []
 
     def local_views(self, S: int) -> Tuple[int, int]:
         return view_partition(S, self.world, self.rank)
@@ -67,6 +81,34 @@ class ViewShard:
         except (RuntimeError, NotImplementedError):
             parts = list(out.view(self.world, *x.shape).unbind(0))
             dist.all_gather(parts, x, group=self.group)
+
+    def gather_kv_groups(self, kv_local: torch.Tensor):
+        """kv_local [G, T_l, D] (contiguous, head-group layout) -> list of G (work, kv_all_g [world*T_l, D]).
+        The G collectives are issued asynchronously, in order; `work.wait()` makes the CURRENT stream wait for that
+        collective only (RCCL) -- the caller overlaps the attention of group g with the transport of g+1.."""
+        assert kv_local.dim() == 3 and kv_local.is_contiguous()
+        G, Tl, D = kv_local.shape
+        out = self._buf("kv_groups", (G, self.world * Tl, D), kv_local)
+        handles = []
+        for g in range(G):
+            try:
+                work = dist.all_gather_into_tensor(out[g], kv_local[g], group=self.group, async_op=True)
+            except (RuntimeError, NotImplementedError):   # backends without the flat variant (gloo)
+                work = dist.all_gather(list(out[g].view(self.world, Tl, D).unbind(0)), kv_local[g], group=self.group,
+                                       async_op=True)
+            handles.append((work, out[g]))
+        return handles
+
+    def side_stream(self, g: int):
+        """Per-head-group CUDA stream (created lazily on the current device)."""
+        while len(self._streams) <= g:
+            self._streams.append(torch.cuda.Stream())
+        return self._streams[g]
+
+    def event(self, i: int):
+        while len(self._events) <= i:
+            self._events.append(torch.cuda.Event())
+        return self._events[i]
 
     def all_gather_rows(self, x_local: torch.Tensor) -> torch.Tensor:
         """[n_l, ...] -> [world*n_l, ...] (camera tokens, small outputs)."""

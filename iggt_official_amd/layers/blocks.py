@@ -181,8 +181,8 @@ class Block(nn.Module):
 
         rope_geom: dict(P=tokens per view, gw=grid width, patch_start=5, cos=..., sin=...) when the block
         has q/k-norm + RoPE (aggregator blocks); None for the DINOv2 blocks.
-        kv_gather: optional callable(kv_local [T, 2C] bf16) -> kv_all [T_all, 2C] (multi-GPU global
-        attention: RCCL all-gather of the post-RoPE K and the V rows).
+        kv_gather: multi-GPU global attention: a dist.ViewShard (K/V all-gather pipelined over head groups when its
+        kv_groups > 1) or a callable(kv_local [T, 2C]) -> kv_all [T_all, 2C]; None on a single GPU.
         """
         if x2d.dtype != torch.float32 or x2d.dim() != 2 or x2d.stride(1) != 1:
             raise _C.HipExtensionError("Block.forward_inplace expects a row-major fp32 [T, C] matrix")
@@ -202,26 +202,56 @@ class Block(nn.Module):
         _C.layernorm(x2d, pk["n1w"], pk["n1b"], xn, self.norm1.eps)
         _C.gemm_h16(xn, pk["w_qkv"], qkv, bias=compensated_bias(ws, xn, pk["dw_qkv"], pk["b_qkv"]))
         k_src, v_src, kv_rs, Nk, k_bs = qkv[:, C:], qkv[:, 2 * C:], 3 * C, tokens, tokens * 3 * C
+        grouped = None
         if self.attn.qk_norm:
             assert rope_geom is not None
+            qk_args = (pk["qw"], pk["qb"], pk["kw"], pk["kb"], rope_geom["cos"], rope_geom["sin"], T, rope_geom["P"],
+                       rope_geom["gw"], rope_geom["patch_start"], self.attn.q_norm.eps)
             if kv_gather is None:
-                _C.qknorm_rope(qkv, qkv, qkv[:, C:], None, pk["qw"], pk["qb"], pk["kw"], pk["kb"],
-                               rope_geom["cos"], rope_geom["sin"], T, rope_geom["P"], rope_geom["gw"],
-                               rope_geom["patch_start"], self.attn.q_norm.eps)
+                _C.qknorm_rope(qkv, qkv, qkv[:, C:], None, *qk_args)
+            elif getattr(kv_gather, "kv_groups", 1) > 1:
+                # multi-GPU, pipelined over head groups (dist.py): K|V of head group g in kv_local[g]
+                assert batch == 1
+                G = kv_gather.kv_groups
+                hg = H // G
+                D = 2 * hg * 64
+                kv_local = ws.get("kv_local", (G, T, D), dt, dev)
+                _C.qknorm_rope(qkv, qkv, kv_local[0], kv_local[0][:, hg * 64:], *qk_args, heads_per_group=hg,
+                               k_group_stride=T * D, v_group_stride=T * D)
+                grouped = (G, hg, D, kv_gather.gather_kv_groups(kv_local))
             else:
+                gather = kv_gather.all_gather_kv if hasattr(kv_gather, "all_gather_kv") else kv_gather
                 kv_local = ws.get("kv_local", (T, 2 * C), dt, dev)
-                _C.qknorm_rope(qkv, qkv, kv_local, kv_local[:, C:], pk["qw"], pk["qb"], pk["kw"], pk["kb"],
-                               rope_geom["cos"], rope_geom["sin"], T, rope_geom["P"], rope_geom["gw"],
-                               rope_geom["patch_start"], self.attn.q_norm.eps)
-                kv_all = kv_gather(kv_local)
+                _C.qknorm_rope(qkv, qkv, kv_local, kv_local[:, C:], *qk_args)
+                kv_all = gather(kv_local)
                 assert batch == 1
                 k_src, v_src, kv_rs, Nk, k_bs = kv_all, kv_all[:, C:], 2 * C, kv_all.shape[0], 0
         elif kv_gather is not None:
             raise _C.HipExtensionError("kv_gather needs a q/k-norm block")
-        with profiling.region("global_attn" if batch == 1 else "frame_attn", (batch, tokens, Nk)):
-            _C.flash_attn_d64(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
-                              tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,
-                              self.attn.scale, q_rows_per_wg)
+        if grouped is None:
+            with profiling.region("global_attn" if batch == 1 else "frame_attn", (batch, tokens, Nk)):
+                _C.flash_attn_d64(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
+                                  tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,
+                                  self.attn.scale, q_rows_per_wg)
+        else:
+            G, hg, D, handles = grouped
+            main = torch.cuda.current_stream()
+            Nk = handles[0][1].shape[0]
+            with profiling.region("global_attn", (1, tokens, Nk)):   # includes the overlapped wait for the gather
+                ready = kv_gather.event(G)
+                ready.record(main)                                    # q (and kv_local) are final on `main`
+                for g, (work, kv_all) in enumerate(handles):
+                    st = kv_gather.side_stream(g)
+                    st.wait_event(ready)
+                    with torch.cuda.stream(st):
+                        if work is not None:
+                            work.wait()                               # this stream waits for collective g only
+                        _C.flash_attn_d64(qkv[:, g * hg * 64:], kv_all, kv_all[:, hg * 64:], ao[:, g * hg * 64:],
+                                          1, hg, tokens, Nk, 0, 3 * C, 0, D, 0, D, 0, C, self.attn.scale,
+                                          q_rows_per_wg)
+                        kv_gather.event(g).record(st)
+                for g in range(G):
+                    main.wait_event(kv_gather.event(g))
         _C.gemm_h16(ao, pk["w_proj"], x2d, bias=compensated_bias(ws, ao, pk["dw_proj"], pk["b_proj"]), gamma=pk["g1"],
                     accumulate=True)
         _C.layernorm(x2d, pk["n2w"], pk["n2b"], xn, self.norm2.eps)

@@ -68,17 +68,21 @@ int iggt_layernorm_f32(const float* x0, long ld0, const float* x1, long ld1, con
                        float eps, int rows_in, int rows_stride, int row_off, int orows_stride, int orow_off,
                        void* stream);
 
-/* Per-head LayerNorm(64) on q,k + 2-D RoPE (+ optional v copy) on a bf16 [T][3*1024] qkv matrix.
- * cos_t/sin_t: fp32 [max_pos+1][16].  Replaces iggt/layers/attention.py:54-58 and
+/* Per-head LayerNorm(64) on q,k + 2-D RoPE (+ optional v copy) on a 16-bit [T][3*1024] qkv matrix.
+ * cos_t/sin_t: fp32 [max_pos+1][16].  heads_per_group in {1,2,4,8} writes k / v in head-group layout -- head h of
+ * token t at out + (h / hpg) * group_stride + t * ld + (h % hpg) * 64 -- so that the multi-GPU K/V all-gather can be
+ * pipelined over head groups (iggt_official_amd/dist.py); 0 or 16: flat rows.  Replaces iggt/layers/attention.py:54-58 and
  * iggt/layers/rope.py:119-188 (positions: iggt/models/aggregator.py:236-245). */
 int iggt_qknorm_rope_bf16(const void* qkv, long ld_in, void* q_out, long ldq, void* k_out, long ldk,
                           void* v_out, long ldv, const float* qw, const float* qb, const float* kw,
                           const float* kb, const float* cos_t, const float* sin_t, int T, int P,
-                          int gw, int patch_start, float eps, void* stream);
+                          int gw, int patch_start, float eps, int heads_per_group, long k_group_stride,
+                          long v_group_stride, void* stream);
 int iggt_qknorm_rope_f16(const void* qkv, long ld_in, void* q_out, long ldq, void* k_out, long ldk,
                          void* v_out, long ldv, const float* qw, const float* qb, const float* kw,
                          const float* kb, const float* cos_t, const float* sin_t, int T, int P,
-                         int gw, int patch_start, float eps, void* stream);
+                         int gw, int patch_start, float eps, int heads_per_group, long k_group_stride,
+                         long v_group_stride, void* stream);
 
 /* ImageNet-normalise + im2row of 14x14 patches: img fp32 [S][3][H][W] -> bf16 (out_f16 = 0) or fp16 (1)
  * [S*gh*gw][Kpad].  Replaces iggt/models/aggregator.py:206 and the unfold half of iggt/layers/patch_embed.py:75. */

@@ -12,6 +12,21 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 
 class FakeShard:
     rank, world = 0, N
+    kv_groups = int(os.environ.get("IGGT_KV_GROUPS", "1"))
+    _streams, _events = [], []
+
+    def gather_kv_groups(self, kv_local):
+        return [(None, kv_local[g].repeat(N, 1)) for g in range(kv_local.shape[0])]
+
+    def side_stream(self, g):
+        while len(self._streams) <= g:
+            self._streams.append(torch.cuda.Stream())
+        return self._streams[g]
+
+    def event(self, i):
+        while len(self._events) <= i:
+            self._events.append(torch.cuda.Event())
+        return self._events[i]
 
     def all_gather_kv(self, kv):
         return kv.repeat(N, 1)

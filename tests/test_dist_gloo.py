@@ -49,6 +49,29 @@ def _worker(rank, world, port, ret):
         assert torch.allclose(mine, full[v0 * P:v1 * P], atol=1e-6)
         cam = torch.randn(S, 2 * C)
         assert torch.equal(shard.all_gather_rows(cam[v0:v1]), cam)
+
+        # head-group pipelined gather: kv_local[g] = [K heads of group g | V heads of group g]; per-group attention
+        # over the gathered group buffers reproduces the same rows
+        G = 2
+        sh2 = ViewShard(kv_groups=G)
+        assert sh2.kv_groups == G
+        hg = H // G
+        loc = kv[v0 * P:v1 * P]
+        kv_local = torch.stack([torch.cat([loc[:, g * hg * D:(g + 1) * hg * D],
+                                           loc[:, C + g * hg * D:C + (g + 1) * hg * D]], 1) for g in range(G)], 0)
+        handles = sh2.gather_kv_groups(kv_local.contiguous())
+        assert len(handles) == G
+        outs = []
+        for g, (work, kv_all_g) in enumerate(handles):
+            if work is not None:
+                work.wait()
+            assert kv_all_g.shape == (S * P, 2 * hg * D)
+            qg = q[v0 * P:v1 * P, g * hg * D:(g + 1) * hg * D].reshape(-1, hg, D).transpose(0, 1)
+            kg = kv_all_g[:, :hg * D].reshape(-1, hg, D).transpose(0, 1)
+            vg = kv_all_g[:, hg * D:].reshape(-1, hg, D).transpose(0, 1)
+            outs.append(torch.nn.functional.scaled_dot_product_attention(qg, kg, vg).transpose(0, 1).reshape(-1, hg * D))
+        assert torch.allclose(torch.cat(outs, 1), full[v0 * P:v1 * P], atol=1e-6)
+        assert ViewShard(kv_groups=None).kv_groups == 1   # pipelining is opt-in (dist.py)
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

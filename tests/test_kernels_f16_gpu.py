@@ -213,3 +213,30 @@ def test_colmean_and_bias_correct(C, dtype, rows, K, step):
     assert float((out.double() - ref).abs().max()) < 1e-6
     C.bias_correct(dw, mu, None, out)
     assert float((out.double() - dw.double() @ mu.double()).abs().max()) < 1e-6
+
+
+def test_qknorm_rope_head_group_layout(C):
+    """k / v written in head-group layout [G][T][K(hg*64) | V(hg*64)] equal the flat outputs, regrouped."""
+    from iggt_official_amd.layers.rope import RotaryPositionEmbedding2D
+
+    S, gh, gw, psi = 2, 3, 4, 5
+    P = psi + gh * gw
+    T = S * P
+    qkv = _rand((T, 3072), 55, 1.5, F16)
+    qw, qb, kw, kb = (_rand((64,), 51) * 0.1 + 1, _rand((64,), 52, 0.1), _rand((64,), 53) * 0.1 + 1,
+                      _rand((64,), 54, 0.1))
+    cos, sin = RotaryPositionEmbedding2D(100).tables(64, max(gh, gw), torch.device("cuda"))
+    flat = torch.empty(T, 2048, dtype=F16, device="cuda")
+    q1 = qkv.clone()
+    C.qknorm_rope(q1, q1, flat, flat[:, 1024:], qw, qb, kw, kb, cos, sin, T, P, gw, psi, 1e-5)
+    for G in (2, 4, 16):
+        hg = 16 // G
+        D = 2 * hg * 64
+        grp = torch.full((G, T, D), float("nan"), dtype=F16, device="cuda")
+        q2 = qkv.clone()
+        C.qknorm_rope(q2, q2, grp[0], grp[0][:, hg * 64:], qw, qb, kw, kb, cos, sin, T, P, gw, psi, 1e-5,
+                      heads_per_group=hg, k_group_stride=T * D, v_group_stride=T * D)
+        assert torch.equal(q2[:, :1024], q1[:, :1024])
+        for g in range(G):
+            assert torch.equal(grp[g][:, :hg * 64], flat[:, g * hg * 64:(g + 1) * hg * 64])
+            assert torch.equal(grp[g][:, hg * 64:], flat[:, 1024 + g * hg * 64:1024 + (g + 1) * hg * 64])

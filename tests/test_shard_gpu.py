@@ -1,8 +1,9 @@
 """Multi-process view sharding on REAL kernels (GPU): two ranks on cuda:0 (gloo transport, because RCCL refuses
 two ranks on one device) each run the sharded IGGT forward on their half of the views; every rank's outputs must
 match the reference fixture for its views at the same tolerance as the unsharded run.  This exercises exactly the
-code path bench.py --gpus N uses (ViewShard K/V all-gather in front of the 24 global attentions, camera-token
-gather), only the transport differs."""
+code path bench.py --gpus N uses (ViewShard K/V all-gather in front of the 24 global attentions -- pipelined over
+head groups with per-group attention launches on side streams, or as one gather -- and the camera-token gather),
+only the transport differs."""
 import os
 import socket
 
@@ -21,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, ret):
+def _worker(rank, world, port, case, kv_groups, ret):
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
@@ -41,7 +42,8 @@ def _worker(rank, world, port, case, ret):
         g = load_golden(case)
         m = g["meta"]
         model = build_gpu_model(m["mode"], m["weight_seed"])
-        shard = ViewShard()
+        shard = ViewShard(kv_groups=kv_groups)   # 1: one gather (default); 4: gather pipelined over head groups
+        assert shard.kv_groups == kv_groups
         model.set_view_shard(shard)
         v0, v1 = shard.local_views(m["S"])
         images = weights.make_images(m["S"], m["H"], m["W"], seed=m["image_seed"], device="cuda")[v0:v1]
@@ -57,13 +59,13 @@ def _worker(rank, world, port, case, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["tiny_s2_56_stress"])
-def test_two_rank_sharded_forward_matches_reference(case):
+@pytest.mark.parametrize("case,kv_groups", [("tiny_s2_56_stress", 4), ("tiny_s2_56_stress", 1)])
+def test_two_rank_sharded_forward_matches_reference(case, kv_groups):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), case, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), case, kv_groups, ret), nprocs=world, join=True)
     assert set(ret.keys()) == {0, 1}
     for rank, res in ret.items():
         for k, l2 in res.items():
-            assert l2 < 1e-2, (rank, k, l2)
+            assert l2 < 1e-3, (rank, k, l2)   # same gate as the unsharded run (fp16 operands)
