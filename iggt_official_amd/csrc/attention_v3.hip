@@ -14,7 +14,10 @@
 //       no ds_write) and 128-key macro tiles (one barrier + one DMA drain per 128 keys)               -> 910 TF/s
 //   +   row-max exchange with lane^32 via v_permlane32_swap (VALU) instead of ds_bpermute (LDS pipe)  -> 940 TF/s
 // Tried and rejected (measured slower): 8-wave ping-pong specialisation (attention.hip, 725), s_setprio around
-// the MFMA groups (855), row sums on the matrix pipe with a ones fragment (880), side-stream tail balancing.
+// the MFMA groups (855), row sums on the matrix pipe with a ones fragment (880), side-stream tail balancing,
+// "optimistic" exponentiation against the stale running max with a post-hoc sum check and a rare redo path instead
+// of the per-tile max tree (-15 % VALU work, but the extra branch splits the block in which QK^T(q1) and exp(q0)
+// interleave: 809 vs 935 TF/s, fp16).
 // Ablation: the same kernel without any softmax VALU work reaches 1 210 TF/s -- the d = 64 softmax (64 exp +
 // ~140 other VALU ops per 32 MFMA) is what separates this kernel from the matrix-pipe limit.
 #include "attention_common.h"
