@@ -27,7 +27,7 @@
 //
 // Tiling: 128 x (32*WN*WAVES_N) output tile, BK = 32, 256 threads; LDS images [rows][32] bf16 with
 // the 16-B slot XOR ((row >> 2) & 3) (conflict-free ds_read_b128 for 64-byte rows), double-buffered,
-// register-staged one K-step ahead.
+// register-staged two K-steps ahead (two register sets).
 #include "common.h"
 #include "../../include/iggt_hip.h"
 
@@ -93,35 +93,64 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     const int chunks_per_tap = p.Cin / BK;
     const int KT = p.KH * p.KW * chunks_per_tap;
 
-    f32x4 ra[4];
-    u32x4 rwh[W_PASSES], rwl[W_PASSES];
-    auto gload = [&](int kt) {
-        const int tap = kt / chunks_per_tap, c0 = (kt - tap * chunks_per_tap) * BK;
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        const int iy = iy0 + ky, ix = ix0 + kx;
-        const bool ok = a_ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-        const float* src = a_base + ((long)(ok ? iy : 0) * p.Wi + (ok ? ix : 0)) * p.ldx + c0;
+    // ---- loader state: chunks are requested strictly in order, so (tap, channel offset) is tracked incrementally
+    //      (no per-chunk integer division) and the tap's pixel pointer / in-bounds flag only change with the tap.
+    int ld_c0 = 0, ld_ky = 0, ld_kx = 0;
+    bool ld_ok = false;
+    const float* ld_src = a_base;
+    auto set_tap = [&]() {
+        const int iy = iy0 + ld_ky, ix = ix0 + ld_kx;
+        ld_ok = a_ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        ld_src = a_base + ((long)(ld_ok ? iy : 0) * p.Wi + (ld_ok ? ix : 0)) * p.ldx;
+    };
+    set_tap();
+    const bf16_t* w_ptr_hi[W_PASSES];
+    const bf16_t* w_ptr_lo[W_PASSES];
+#pragma unroll
+    for (int q = 0; q < W_PASSES; ++q) {
+        int r = n0 + w_row + 64 * q;
+        if (BN < 64 && w_row >= BN) r = n0;  // BN == 32: upper half of the threads duplicate row 0
+        r = r < p.Cout ? r : p.Cout - 1;
+        w_ptr_hi[q] = p.w_hi + (long)r * Ktot + w_piece * 8;
+        w_ptr_lo[q] = (PREC == 3) ? p.w_lo + (long)r * Ktot + w_piece * 8 : nullptr;
+    }
+    int w_k = 0;  // running K offset (elements) of the weight loads
+    const float relu_floor = p.relu_in ? 0.f : -INFINITY;  // fused ReLU-on-load as one v_max (x = max(x, floor))
+
+    // Two register sets: the loads of chunk kt+2 are in flight while chunk kt is multiplied and chunk kt+1 is written
+    // to LDS (one set was measured to leave the waves parked on vmcnt 45 % of the time, profiles/r01_conv_pmc.txt).
+    struct Stage {
+        f32x4 ra[4];
+        u32x4 rwh[W_PASSES], rwl[W_PASSES];
+    };
+    Stage R0, R1;
+    auto gload = [&](Stage& R) {
+        const float* src = ld_src + ld_c0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * i);
-            if (!ok) t = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.relu_in) {
+            if (!ld_ok) t = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = fmaxf(t[e], 0.f);
-            }
-            ra[i] = t;
+            for (int e = 0; e < 4; ++e) t[e] = fmaxf(t[e], relu_floor);
+            R.ra[i] = t;
         }
 #pragma unroll
         for (int q = 0; q < W_PASSES; ++q) {
-            int r = n0 + w_row + 64 * q;
-            if (BN < 64 && w_row >= BN) r = n0;  // BN == 32: upper half of the threads duplicate row 0
-            r = r < p.Cout ? r : p.Cout - 1;
-            const long off = (long)r * Ktot + (long)kt * BK + w_piece * 8;
-            rwh[q] = *reinterpret_cast<const u32x4*>(p.w_hi + off);
-            if (PREC == 3) rwl[q] = *reinterpret_cast<const u32x4*>(p.w_lo + off);
+            R.rwh[q] = *reinterpret_cast<const u32x4*>(w_ptr_hi[q] + w_k);
+            if (PREC == 3) R.rwl[q] = *reinterpret_cast<const u32x4*>(w_ptr_lo[q] + w_k);
+        }
+        w_k += BK;
+        ld_c0 += BK;
+        if (ld_c0 == p.Cin) {  // wave-uniform: next tap
+            ld_c0 = 0;
+            if (++ld_kx == p.KW) {
+                ld_kx = 0;
+                ++ld_ky;
+            }
+            set_tap();
         }
     };
-    auto swrite = [&](int buf) {
+    auto swrite = [&](int buf, const Stage& R) {
         char* sAh = smem + buf * STAGE;
         char* sWh = sAh + A_BYTES;
         char* sAl = sWh + W_BYTES;  // PREC == 3 only
@@ -131,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float x0 = ra[2 * i + (e >> 1)][2 * (e & 1)], x1 = ra[2 * i + (e >> 1)][2 * (e & 1) + 1];
+                const float x0 = R.ra[2 * i + (e >> 1)][2 * (e & 1)], x1 = R.ra[2 * i + (e >> 1)][2 * (e & 1) + 1];
                 const uint32_t hp = pack_bf16x2(x0, x1);
                 h[i][e] = hp;
                 if (PREC == 3) l[i][e] = pack_bf16x2(x0 - bf16_lo(hp), x1 - bf16_hi(hp));
@@ -147,8 +176,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             const int r = w_row + 64 * q;
             if (r < BN) {
                 const int off = slot_swz(r, w_piece);
-                *reinterpret_cast<u32x4*>(sWh + off) = rwh[q];
-                if (PREC == 3) *reinterpret_cast<u32x4*>(sWl + off) = rwl[q];
+                *reinterpret_cast<u32x4*>(sWh + off) = R.rwh[q];
+                if (PREC == 3) *reinterpret_cast<u32x4*>(sWl + off) = R.rwl[q];
             }
         }
     };
@@ -162,12 +191,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int frow = lane & 31, fhalf = lane >> 5;
-    gload(0);
-    swrite(0);
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) gload(kt + 1);
-        const char* sAh = smem + (kt & 1) * STAGE;
+    auto compute = [&](int buf) {
+        const char* sAh = smem + buf * STAGE;
         const char* sWh = sAh + A_BYTES;
         const char* sAl = sWh + W_BYTES;
         const char* sWl = sAl + A_BYTES;
@@ -197,7 +222,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
                     acc[i][j] = mfma32(ah[i], bh[j], acc[i][j]);
                 }
         }
-        if (kt + 1 < KT) swrite((kt + 1) & 1);
+    };
+    gload(R0);            // chunk 0
+    if (KT > 1) gload(R1);  // chunk 1
+    swrite(0, R0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; kt += 2) {
+        // even step: chunk kt in LDS buffer 0, chunk kt+1 in R1, request chunk kt+2 into R0
+        if (kt + 2 < KT) gload(R0);
+        compute(0);
+        if (kt + 1 < KT) swrite(1, R1);
+        __syncthreads();
+        if (kt + 1 >= KT) break;
+        // odd step: chunk kt+1 in buffer 1, chunk kt+2 in R0, request chunk kt+3 into R1
+        if (kt + 3 < KT) gload(R1);
+        compute(1);
+        if (kt + 2 < KT) swrite(0, R0);
         __syncthreads();
     }
 
