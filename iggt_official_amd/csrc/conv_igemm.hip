@@ -56,7 +56,12 @@ struct ConvParams {
 
 constexpr int BK = 32;
 
-IGGT_DEVINL int slot_swz(int row, int slot) { return row * 64 + (((slot ^ (row >> 2)) & 3) << 4); }
+// key = (row>>2)&3 keeps ds_read_b128's 16-lane groups conflict-free (rows with equal row%4 get distinct slots); the
+// extra ^ ((row>>1)&1) gives rows r and r+2 -- same 128-byte window of the ds_write_b128 bank map, written by one
+// 8-lane group of the A loader -- different slots (PMC: 2-way write conflicts on 20 % of the LDS cycles before).
+IGGT_DEVINL int slot_swz(int row, int slot) {
+    return row * 64 + (((slot ^ (row >> 2) ^ ((row >> 1) & 1)) & 3) << 4);
+}
 
 template <int PREC, int WM, int WN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {

@@ -8,6 +8,7 @@ from iggt.models.vggt import IGGT
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+SIZE = int(sys.argv[3]) if len(sys.argv) > 3 else 518
 
 
 class FakeShard:
@@ -39,11 +40,11 @@ torch.manual_seed(0)
 with torch.device("cuda"):
     model = IGGT(part_on_invalid_grid="skip").eval()
 model.set_view_shard(FakeShard())
-img = torch.rand(S // N, 3, 518, 518, device="cuda")
-for i in range(4):
+img = torch.rand(S // N, 3, SIZE, SIZE, device="cuda")
+for i in range(3 if SIZE > 518 else 4):
     torch.cuda.synchronize(); t = time.perf_counter()
     model(img)
     t_host = time.perf_counter() - t
     torch.cuda.synchronize(); t_all = time.perf_counter() - t
-    print(f"N={N} local views={S//N}: host-side launch time {t_host*1e3:.1f} ms, forward {t_all*1e3:.1f} ms "
+    print(f"N={N} local views={S//N} @{SIZE}: peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB, host-side launch time {t_host*1e3:.1f} ms, forward {t_all*1e3:.1f} ms "
           f"-> {S/t_all:.1f} views/s if comm were free")
