@@ -12,7 +12,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -42,6 +42,8 @@ _SIGNATURES = {
     "iggt_im2row_patch14": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p],
     "iggt_colmean_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "iggt_bias_correct_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
+    "iggt_head_tail_f32": [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int,
+                           _c_int, _c_void_p],
     "iggt_conv2d_nhwc_f32": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                              _c_int]
                             + [_c_int] * 24 + [_c_void_p],
@@ -212,6 +214,27 @@ def bias_correct(dw, mu, bias, out):
                                       _ptr(bias), out.data_ptr(), int(dw.dtype == torch.float16), _stream())
     _check(rc, "iggt_bias_correct_h16")
     return out
+
+
+HEAD_ACT = {"linear": 0, "exp": 1, "relu": 2, "inv_log": 3, "sigmoid": 4, "norm": 5}
+CONF_ACT = {"expp1": 0, "expp0": 1, "sigmoid": 2}
+
+
+def head_tail(x, w, b, activation, conf_activation):
+    """x NHWC fp32 [..., 32] -> (pts [..., Cout-1], conf [...]): 1x1 conv + activate_head (include/iggt_hip.h)."""
+    _dev(x, w, b)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] >= 32
+    Cout = w.shape[0]
+    assert w.shape[1] == 32 and w.is_contiguous() and b.is_contiguous() and w.dtype == torch.float32
+    lead = x.shape[:-1]
+    npix = x.numel() // x.shape[-1]
+    pts = torch.empty(*lead, Cout - 1, dtype=torch.float32, device=x.device)
+    conf = torch.empty(*lead, dtype=torch.float32, device=x.device)
+    rc = load().iggt_head_tail_f32(x.data_ptr(), x.shape[-1], w.data_ptr(), b.data_ptr(), pts.data_ptr(),
+                                   conf.data_ptr(), npix, Cout, HEAD_ACT[activation], CONF_ACT[conf_activation],
+                                   _stream())
+    _check(rc, "iggt_head_tail_f32")
+    return pts, conf
 
 
 def write_special_tokens(dst, src0, src1, S, nrows, row_off, first_view_is_zero):

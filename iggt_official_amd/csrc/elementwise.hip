@@ -318,6 +318,71 @@ __global__ __launch_bounds__(256) void bias_correct_kernel(const BiasCorrParams 
     if (lane == 0) p.out[n] = acc + (p.bias ? p.bias[n] : 0.f);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tail of the DPT heads: 1x1 convolution 32 -> Cout (2..8) on an NHWC fp32 map fused with activate_head.
+// Reference: scratch.output_conv2[2] (iggt/heads/dpt_head.py:121-128) + activate_head (iggt/heads/head_act.py:61-125):
+// the first Cout-1 channels go through `act` (0 linear, 1 exp, 2 relu, 3 inv_log = sign(x) expm1(|x|), 4 sigmoid,
+// 5 x / ||x||), the last one through `conf_act` (0 1 + exp, 1 exp, 2 sigmoid).
+// HBM-bound (128 B in, <= 16 B out per pixel): 8 lanes per pixel, one float4 of the 32 channels each, 3-step xor
+// reduction, lane o of the group finishes output o.  fp32 throughout (the reference runs this stage in fp32).
+struct TailParams {
+    const float* x;
+    long ldx;
+    const float* w;   // [Cout][32]
+    const float* b;   // [Cout]
+    float* pts;       // [npix][Cout-1]
+    float* conf;      // [npix]
+    long npix;
+    int Cout, act, conf_act;
+};
+
+__global__ __launch_bounds__(256) void head_tail_kernel(const TailParams p) {
+    const int sub = threadIdx.x & 7;
+    float wreg[8][4], breg[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const bool on = o < p.Cout;
+        const f32x4 wv = on ? *reinterpret_cast<const f32x4*>(p.w + o * 32 + sub * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wreg[o][e] = wv[e];
+        breg[o] = on ? p.b[o] : 0.f;
+    }
+    const long groups = (long)gridDim.x * 32;
+    for (long pix = (long)blockIdx.x * 32 + (threadIdx.x >> 3); pix < p.npix; pix += groups) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + pix * p.ldx + sub * 4);
+        float acc[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float t = v[0] * wreg[o][0] + v[1] * wreg[o][1] + v[2] * wreg[o][2] + v[3] * wreg[o][3];
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 4, 64);
+            acc[o] = t + breg[o];
+        }
+        float mine = 0.f, nrm2 = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            if (o == sub) mine = acc[o];
+            if (o < p.Cout - 1) nrm2 += acc[o] * acc[o];
+        }
+        if (sub < p.Cout - 1) {
+            float r = mine;
+            if (p.act == 1) r = expf(mine);
+            else if (p.act == 2) r = fmaxf(mine, 0.f);
+            else if (p.act == 3) r = copysignf(expm1f(fabsf(mine)), mine);
+            else if (p.act == 4) r = 1.0f / (1.0f + expf(-mine));
+            else if (p.act == 5) r = mine / sqrtf(nrm2);
+            p.pts[pix * (p.Cout - 1) + sub] = r;
+        } else if (sub == p.Cout - 1) {
+            float r;
+            if (p.conf_act == 0) r = 1.0f + expf(mine);
+            else if (p.conf_act == 1) r = expf(mine);
+            else r = 1.0f / (1.0f + expf(-mine));
+            p.conf[pix] = r;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int iggt_layernorm_f32(const float* x0, long ld0, const float* x1, long ld1, const float* w,
@@ -439,6 +504,20 @@ extern "C" int iggt_bias_correct_h16(const void* dw, long ldw, int N, int K, con
     const dim3 grid((N + 3) / 4), block(256);
     if (f16) hipLaunchKernelGGL(bias_correct_kernel<FMT_F16>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(bias_correct_kernel<FMT_BF16>, grid, block, 0, (hipStream_t)stream, p);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int iggt_head_tail_f32(const float* x, long ldx, const float* w, const float* b, float* pts, float* conf,
+                                  long npix, int Cout, int act, int conf_act, void* stream) {
+    if (npix <= 0 || Cout < 2 || Cout > 8 || (ldx % 4) != 0 || ldx < 32) return -1;
+    if (act < 0 || act > 5 || conf_act < 0 || conf_act > 2) return -2;
+    TailParams p;
+    p.x = x; p.ldx = ldx; p.w = w; p.b = b; p.pts = pts; p.conf = conf; p.npix = npix;
+    p.Cout = Cout; p.act = act; p.conf_act = conf_act;
+    long blocks = (npix + 31) / 32;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(head_tail_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
     return 0;
 }

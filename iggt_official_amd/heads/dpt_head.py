@@ -225,8 +225,15 @@ class DPTHead(nn.Module):
             return out.permute(0, 3, 1, 2)[None]
         c2 = self.scratch.output_conv2
         out = co.run(self._conv("oc2_0", c2[0]), out, act=1)                 # conv3x3 128->32 + ReLU
-        out = F.linear(out, c2[2].weight.view(c2[2].out_channels, -1), c2[2].bias)   # 1x1, 32 -> 4|2 (NHWC)
-        preds, conf = self._activate(out)
+        if (c2[2].in_channels == 32 and 2 <= c2[2].out_channels <= 8 and self.activation in _C.HEAD_ACT
+                and self.conf_activation in _C.CONF_ACT):
+            # 1x1 conv 32 -> 4|2 + activate_head in one HBM pass (csrc/elementwise.hip head_tail_kernel)
+            preds, conf = _C.head_tail(out, c2[2].weight.detach().float().reshape(c2[2].out_channels, 32).contiguous(),
+                                       c2[2].bias.detach().float().contiguous(), self.activation,
+                                       self.conf_activation)
+        else:
+            out = F.linear(out, c2[2].weight.view(c2[2].out_channels, -1), c2[2].bias)
+            preds, conf = self._activate(out)
         preds = preds.reshape(1, S, *preds.shape[1:])
         conf = conf.reshape(1, S, *conf.shape[1:])
         return (preds, conf, side) if self.use_point_feat else (preds, conf)

@@ -88,6 +88,13 @@ int iggt_qknorm_rope_f16(const void* qkv, long ld_in, void* q_out, long ldq, voi
  * [S*gh*gw][Kpad].  Replaces iggt/models/aggregator.py:206 and the unfold half of iggt/layers/patch_embed.py:75. */
 int iggt_im2row_patch14(const float* img, void* out, int out_f16, int S, int H, int W, int Kpad, void* stream);
 
+/* Tail of the DPT heads on an NHWC fp32 map x [npix][ldx] (32 input channels): 1x1 convolution to Cout (2..8)
+ * channels + activate_head: pts [npix][Cout-1] = act(first Cout-1 channels), conf [npix] = conf_act(last channel).
+ * act: 0 linear, 1 exp, 2 relu, 3 inv_log, 4 sigmoid, 5 norm;  conf_act: 0 expp1, 1 expp0, 2 sigmoid.
+ * Replaces scratch.output_conv2[2] (iggt/heads/dpt_head.py:121-128) and iggt/heads/head_act.py:61-125. */
+int iggt_head_tail_f32(const float* x, long ldx, const float* w, const float* b, float* pts, float* conf,
+                       long npix, int Cout, int act, int conf_act, void* stream);
+
 /* Mean-input compensation of the 16-bit weight rounding (no counterpart in the reference, which is fp32 on the
  * CPU path this repository is checked against; see iggt_official_amd/precision.py):
  *   iggt_colmean_h16:      mu[k] = mean over rows 0, row_step, 2*row_step, ... of the 16-bit matrix x [rows][K]

@@ -296,3 +296,18 @@ def test_gemm_large_tile_path(C, M, N, K, mode):
             assert not torch.isnan(out).any() and _relerr(out[rows], base_s)[0] < 2e-5
         else:
             assert _relerr(out, base)[0] < 2e-5
+
+
+@pytest.mark.parametrize("Cout,act,conf_act", [(4, "inv_log", "expp1"), (2, "exp", "expp1"), (4, "norm", "sigmoid"),
+                                               (8, "linear", "expp0"), (3, "relu", "expp1"), (4, "sigmoid", "expp1")])
+def test_head_tail(C, Cout, act, conf_act):
+    """1x1 conv 32 -> Cout + activate_head, fp32 (reference dpt_head.py:121-128, head_act.py:61-125)."""
+    from iggt_official_amd.heads.head_act import activate_head
+
+    x = _rand((3, 37, 41, 32), 80, 0.7)
+    w, b = _rand((Cout, 32), 81, 0.2), _rand((Cout,), 82, 0.3)
+    pts, conf = C.head_tail(x, w, b, act, conf_act)
+    lin = torch.nn.functional.linear(x.double(), w.double(), b.double())            # NHWC
+    rp, rc = activate_head(lin.permute(0, 3, 1, 2), activation=act, conf_activation=conf_act)
+    assert pts.shape == rp.shape and conf.shape == rc.shape
+    assert _relerr(pts, rp)[0] < 2e-6 and _relerr(conf, rc)[0] < 2e-6
