@@ -17,7 +17,9 @@
 // the MFMA groups (855), row sums on the matrix pipe with a ones fragment (880), side-stream tail balancing,
 // "optimistic" exponentiation against the stale running max with a post-hoc sum check and a rare redo path instead
 // of the per-tile max tree (-15 % VALU work, but the extra branch splits the block in which QK^T(q1) and exp(q0)
-// interleave: 809 vs 935 TF/s, fp16).
+// interleave: 809 vs 935 TF/s, fp16); a mixed-tile launch that hands the last, 37 %-full round of 256-row tiles to
+// 128-row tiles (correct, but 1.5 % slower: a CU left with ONE resident workgroup already runs it ~1.7x faster, so
+// the partial round costs ~0.6 of a full one, not 1.0).
 // Ablation: the same kernel without any softmax VALU work reaches 1 210 TF/s -- the d = 64 softmax (64 exp +
 // ~140 other VALU ops per 32 MFMA) is what separates this kernel from the matrix-pipe limit.
 #include "attention_common.h"
