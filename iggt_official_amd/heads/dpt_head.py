@@ -99,6 +99,12 @@ def _make_scratch(in_shape, out_shape, groups=1, expand=False):
     return scratch
 
 
+# Frames per head pass.  The reference defaults to 8 to bound memory on 24-80 GB GPUs (dpt_head.py:133); with 288 GB
+# of HBM 32 frames fit easily (largest maps: 32 x 518^2 x 128 fp32 = 4.4 GB) and the larger launches fill the chip
+# better: 70.0 / 71.6 / 72.2 views/s at 8 / 16 / 32 (32 views @ 518^2).  Results do not depend on it.
+FRAMES_CHUNK = 32
+
+
 class TokenProjector:
     """LayerNorm(2C) + 1x1 conv on patch tokens, in HIP.  Shared by DPTHead and the adaptors."""
 
@@ -175,7 +181,7 @@ class DPTHead(nn.Module):
     def _conv(self, key, conv):
         return self._pk.get(key, (conv.weight, conv.bias), lambda: co.pack_conv2d(conv))
 
-    def forward(self, aggregated_tokens_list, images, patch_start_idx, frames_chunk_size=8):
+    def forward(self, aggregated_tokens_list, images, patch_start_idx, frames_chunk_size=FRAMES_CHUNK):
         """Returns (preds [1,S,H,W,c], conf [1,S,H,W][, (out2,out3,out4) NHWC fusion features])."""
         B, S, _, H, W = images.shape
         if B != 1:
