@@ -61,7 +61,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256pp_kernel(const GemmPara
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int v = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = v / p.tiles_n, tn = v - tm * p.tiles_n;
+    // Tile order inside an XCD's contiguous chunk: groups of group_m row-tiles, m fastest inside a group, so the ~32
+    // tiles an XCD runs concurrently form a (group_m x 32/group_m) block instead of a (32/tiles_n x tiles_n) strip --
+    // fewer distinct A / W slices per K step have to come from beyond the L2.
+    int tm, tn;
+    if (p.group_m > 1) {
+        const int per_group = p.group_m * p.tiles_n;
+        const int grp = v / per_group, in = v - grp * per_group;
+        const int first = grp * p.group_m;
+        const int gsz = (p.tiles_m - first) < p.group_m ? (p.tiles_m - first) : p.group_m;
+        tn = in / gsz;
+        tm = first + (in - tn * gsz);
+    } else {
+        tm = v / p.tiles_n;
+        tn = v - tm * p.tiles_n;
+    }
     const int m0 = tm * TM, n0 = tn * TN;
 
     const int c_row = lane >> 2, c_pos = lane & 3;
@@ -247,6 +261,13 @@ int iggt_launch_gemm_t256(const GemmParams& p_in, int fmt, hipStream_t stream) {
     if (p.K / TK < 4) return -100;      // the pipeline prologue needs 3 stages
     p.tiles_n = (p.N + TN - 1) / TN;
     const int tiles_m = (p.M + TM - 1) / TM;
+    p.tiles_m = tiles_m;
+    static int gm = -1;
+    if (gm < 0) {
+        const char* e = getenv("IGGT_GEMM_GROUP_M");
+        gm = e ? atoi(e) : 4;   // measured at M=43968: qkv 695-717 -> 734-742 TF/s, fc1 679-683 -> 692-696 (GM 2 / 8: no gain)
+    }
+    p.group_m = (p.tiles_n > 4) ? gm : 0;
     int mode;
     if (p.out_bf16 && !p.gamma && p.rows_in == 0) mode = 1;
     else if (p.out_f32 && p.accumulate && p.rows_in == 0 && p.act == 0) mode = 2;

@@ -8,6 +8,7 @@ struct GemmParams {
     int M, N, K;
     long lda, ldw;
     int tiles_n;
+    int tiles_m, group_m;  // big-tile kernel: tile order grouped over group_m row-tiles (0: n-fastest)
     // epilogue
     const float* bias;       // [N] or null
     const float* gamma;      // [N] or null
