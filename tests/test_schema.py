@@ -30,3 +30,26 @@ def test_relative_position_buffers_match_reference():
                        ints["part_head.window_cross_attention.relative_position_index_OCA"])
     assert torch.equal(ca.relative_position_index_SA,
                        ints["part_head.window_cross_attention.relative_position_index_SA"])
+
+
+def test_alias_package_falls_through_to_reference_for_off_path_modules():
+    """demo.py imports iggt.models.vggt (provided here) AND iggt.utils.* (not provided: off the hot path).  With this
+    repository in front of a reference checkout on PYTHONPATH the first resolves here, the second to the reference."""
+    import os
+    import subprocess
+    import sys
+
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "iggt", "utils")):
+        import pytest
+
+        pytest.skip("no reference checkout on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import iggt.models.vggt as v, iggt.utils.pose_enc as pe, iggt.heads.dpt_head as d;"
+            "print(v.__file__); print(pe.__file__); print(d.__file__)")
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + ref)
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()[-3:]
+    assert lines[0].startswith(root) and lines[2].startswith(root), lines
+    assert lines[1].startswith(ref), lines
