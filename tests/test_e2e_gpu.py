@@ -126,3 +126,22 @@ def test_no_cpu_fallback():
     model = build_gpu_model("stress", 0)
     with pytest.raises(HipExtensionError):
         model(torch.rand(2, 3, 56, 56))  # CPU tensor: must raise, never fall back
+
+
+def test_single_view_matches_oracle():
+    """S = 1 (no fixture: checked against the CPU restatement, which is pinned to the reference by
+    tests/test_oracle_golden.py): only slot 0 of camera_token / register_token is used (aggregator.py:338-361)."""
+    from oracle import restate, weights
+    from helpers import schema
+
+    model = build_gpu_model("stress", 0)
+    images = weights.make_images(1, 56, 84, seed=5, device="cuda")
+    pred = model(images)
+    torch.cuda.synchronize()
+    sd = {k: v.cpu() for k, v in weights.fill_state_dict(schema(), seed=0, mode="stress", device="cuda").items()}
+    with torch.no_grad():
+        ref = restate.iggt_forward(sd, images.cpu(), with_part=True)
+    for k in ("depth", "depth_conf", "world_points", "world_points_conf", "part_feat"):
+        e = errors(pred[k], ref[k])
+        assert e[1] < 1e-3, (k, e)
+    assert errors(torch.stack(pred["pose_enc"], 0), torch.stack(ref["pose_enc"], 0))[1] < 1e-3
