@@ -85,6 +85,41 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
     }
 }
 
+// LayerNorm over C = 128 (window-attention stages of the part head, iggt/heads/window_sa.py:176-181,330-333):
+// 32 lanes x one float4 per row, two rows per wave, same two-pass arithmetic; no concat / row remap.
+__global__ __launch_bounds__(256) void layernorm128_kernel(const LnParams p) {
+    const int sub = threadIdx.x & 31;
+    const long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= p.rows) return;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p.x0 + row * p.ld0 + sub * 4);
+    float s = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.0f / 128);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float d = v[e] - mean;
+        q += d * d;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q * (1.0f / 128) + p.eps);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + sub * 4);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b + sub * 4);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = (v[e] - mean) * rstd * w[e] + bb[e];
+    if (p.out_f32) {
+        *reinterpret_cast<f32x4*>(p.out_f32 + row * p.ldo + sub * 4) = y;
+    } else {
+        u32x2 o;
+        o[0] = p.f16 ? pack_h2<FMT_F16>(y[0], y[1]) : pack_h2<FMT_BF16>(y[0], y[1]);
+        o[1] = p.f16 ? pack_h2<FMT_F16>(y[2], y[3]) : pack_h2<FMT_BF16>(y[2], y[3]);
+        *reinterpret_cast<u32x2*>(p.out + row * p.ldo + sub * 4) = o;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-head LayerNorm(64) on q and k followed by 2-D RoPE; optional copy of v.
 // Reference: iggt/layers/attention.py:54-58 (q_norm/k_norm then rope) and
@@ -406,6 +441,8 @@ extern "C" int iggt_layernorm_f32(const float* x0, long ld0, const float* x1, lo
     else if (C == 2048) hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, st, p);
     else if (C == 256 && !x1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, p);
     else if (C == 512 && !x1) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, p);
+    else if (C == 128 && !x1 && rows_in == 0)
+        hipLaunchKernelGGL(layernorm128_kernel, dim3((rows + 7) / 8), block, 0, st, p);
     else return -3;
     IGGT_CHECK_LAUNCH();
     return 0;

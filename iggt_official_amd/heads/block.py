@@ -3,12 +3,15 @@
 The reference runs xformers' memory-efficient attention when available and an explicit
 softmax(q k^T * scale) v otherwise (block.py:132-136, 225-229); both are the same function.  Here the
 attention core is `F.scaled_dot_product_attention` on the GPU in fp32 (head dim 32: the head-dim-64
-HIP flash kernel does not apply; DESIGN.md lists a d=32 variant as next).  qk_norm / rope are never
+HIP flash kernel does not apply; DESIGN.md lists a d=32 variant as next); the q/k/v/proj Linear layers run on the
+split-bf16 HIP GEMM (heads/tokenops.py).  qk_norm / rope are never
 enabled by IGGT (part_head.py:74,83; window_sa.py:193) and are not built.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import tokenops as tk
 
 
 class Attention(nn.Module):
@@ -25,9 +28,9 @@ class Attention(nn.Module):
 
     def forward(self, x, xpos=None):
         B, N, C = x.shape
-        qkv = self.qkv(x).view(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+        qkv = tk.linear(self.qkv, x).view(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
         o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], scale=self.scale)
-        return self.proj(o.transpose(1, 2).reshape(B, N, C))
+        return tk.linear(self.proj, o.transpose(1, 2).reshape(B, N, C))
 
 
 MemEffAttention = Attention
@@ -51,11 +54,11 @@ class CrossAttention(nn.Module):
     def forward(self, query, key, value, qpos=None, kpos=None):
         B, Nq, C = query.shape
         h, d = self.num_heads, self.head_dim
-        q = self.projq(query).view(B, Nq, h, d).transpose(1, 2)
-        k = self.projk(key).view(B, key.shape[1], h, d).transpose(1, 2)
-        v = self.projv(value).view(B, value.shape[1], h, d).transpose(1, 2)
+        q = tk.linear(self.projq, query).view(B, Nq, h, d).transpose(1, 2)
+        k = tk.linear(self.projk, key).view(B, key.shape[1], h, d).transpose(1, 2)
+        v = tk.linear(self.projv, value).view(B, value.shape[1], h, d).transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
-        return self.proj(o.transpose(1, 2).reshape(B, Nq, C))
+        return tk.linear(self.proj, o.transpose(1, 2).reshape(B, Nq, C))
 
 
 class MemEffCrossAttention(CrossAttention):

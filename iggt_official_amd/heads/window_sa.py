@@ -13,14 +13,17 @@ Two reference behaviours are reproduced on purpose because trained weights depen
   * map sizes must be multiples of the window (8): the reference fails in calculate_mask
     (window_sa.py:401-415); here a ValueError states the constraint.
 Execution: NHWC fp32; every 3x3 convolution (CAB, conv_after_body, conv_before_upsample, conv_last) runs on
-the implicit-GEMM MFMA kernel (csrc/conv_igemm.hip; CAB's 42-channel bottleneck is zero-padded to 64); the
-window attention cores (head dim 32) and the small Linear/LayerNorm layers run on PyTorch-ROCm fp32 ops.
+the implicit-GEMM MFMA kernel (csrc/conv_igemm.hip; CAB's 42-channel bottleneck is zero-padded to 64); LayerNorms
+and Linear layers (q/k/v/proj, MLPs with fused GELU and residual adds) run on HIP kernels through heads/tokenops.py;
+only the head-dim-32 window attention cores (8x8 queries, 64 / 144 keys) and the window gather/scatter copies are
+PyTorch-ROCm fp32 ops.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import convops as co
+from . import tokenops as tk
 from .block import MemEffAttention
 
 
@@ -87,8 +90,12 @@ class Mlp(nn.Module):
         self.act = act_layer()
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
 
-    def forward(self, x):
-        return self.fc2(self.act(self.fc1(x)))
+    def forward(self, x, res=None):
+        """fc2(GELU(fc1(x))) (+ res): both Linears on the HIP kernel, GELU and the residual add fused (tokenops)."""
+        act = 3 if isinstance(self.act, nn.GELU) else None
+        if act is None:
+            return tk.linear(self.fc2, self.act(tk.linear(self.fc1, x)), res=res)
+        return tk.linear(self.fc2, tk.linear(self.fc1, x, act=act), res=res)
 
 
 class _TokenNorm(nn.Module):
@@ -120,12 +127,12 @@ class HAB(nn.Module):
         h, w = x_size
         b, _, c = x.shape
         ws = self.window_size
-        y = self.norm1(x).view(b, h, w, c)
+        y = tk.layer_norm(self.norm1, x).view(b, h, w, c)
         conv_x = self.conv_block.forward_nhwc(y.contiguous()).reshape(b, h * w, c)
         win = window_partition(y, ws).view(-1, ws * ws, c)
         att = window_reverse(self.attn(win).view(-1, ws, ws, c), ws, h, w).view(b, h * w, c)
         x = x + att + conv_x * self.conv_scale
-        return x + self.mlp(self.norm2(x))
+        return self.mlp(tk.layer_norm(self.norm2, x), res=x)
 
 
 def _ocab_query_windows(q_bhwc, ws):
@@ -161,9 +168,9 @@ class OCAB(nn.Module):
         ws, ow, nh = self.window_size, self.overlap_win_size, self.num_heads
         d = c // nh
         shortcut = x
-        q = self.q(self.norm1(x)).view(b, h, w, c)
-        kk = self.k(self.norm1(k)).view(b, h, w, c).permute(0, 3, 1, 2)
-        vv = self.v(self.norm1(v)).view(b, h, w, c).permute(0, 3, 1, 2)
+        q = tk.linear(self.q, tk.layer_norm(self.norm1, x)).view(b, h, w, c)
+        kk = tk.linear(self.k, tk.layer_norm(self.norm1, k)).view(b, h, w, c).permute(0, 3, 1, 2)
+        vv = tk.linear(self.v, tk.layer_norm(self.norm1, v)).view(b, h, w, c).permute(0, 3, 1, 2)
         qw = _ocab_query_windows(q, ws)                                              # [b*nw, 64, c]
         pad = (ow - ws) // 2
         kv = F.unfold(torch.cat((kk, vv), 1), kernel_size=(ow, ow), stride=ws, padding=pad)  # [b, 2c*ow*ow, nw]
@@ -175,8 +182,8 @@ class OCAB(nn.Module):
         bias = self.relative_position_bias_table[rpi.reshape(-1)].view(ws * ws, ow * ow, nh).permute(2, 0, 1)
         o = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=bias.unsqueeze(0).contiguous(), scale=self.scale)
         o = o.transpose(1, 2).reshape(-1, ws, ws, c)
-        x = self.proj(window_reverse(o, ws, h, w).view(b, h * w, c)) + shortcut
-        return x + self.mlp(self.norm2(x))
+        x = tk.linear(self.proj, window_reverse(o, ws, h, w).view(b, h * w, c), res=shortcut)
+        return self.mlp(tk.layer_norm(self.norm2, x), res=x)
 
 
 class SwinSA(nn.Module):
@@ -224,8 +231,8 @@ class SwinSA(nn.Module):
         x = x.contiguous()
         b, h, w, c = x.shape
         _check_window_grid(h, w, self.window_size)
-        t = self.atten_block(self.patch_embed.norm(x.view(b, h * w, c)), (h, w))
-        body = self.norm(t).view(b, h, w, c)
+        t = self.atten_block(tk.layer_norm(self.patch_embed.norm, x.view(b, h * w, c)), (h, w))
+        body = tk.layer_norm(self.norm, t).view(b, h, w, c)
         return self._tail(body, x)
 
 
@@ -259,7 +266,7 @@ class SwinCA(SwinSA):
         x = x.contiguous()
         b, h, w, c = x.shape
         _check_window_grid(h, w, self.window_size)
-        tn = lambda z: self.patch_embed.norm(z.reshape(b, h * w, c))  # noqa: E731
+        tn = lambda z: tk.layer_norm(self.patch_embed.norm, z.reshape(b, h * w, c))  # noqa: E731
         t = self.atten_block(tn(x), tn(k), tn(v), (h, w), self.relative_position_index_OCA)
-        body = self.norm(t).view(b, h, w, c)
+        body = tk.layer_norm(self.norm, t).view(b, h, w, c)
         return self._tail(body, x)

@@ -58,11 +58,11 @@ int iggt_flash_attn_f16_d64(const void* q, const void* k, const void* v, void* o
                             long v_bs, long v_rs, long o_bs, long o_rs, float scale,
                             int q_rows_per_wg, void* stream);
 
-/* LayerNorm over C in {256,512,1024,2048}; fp32 in ((x0|x1) concatenation when x1 != NULL); out_type 0 = bf16,
+/* LayerNorm over C in {128 (no concat / remap), 256, 512, 1024, 2048}; fp32 in ((x0|x1) concatenation when x1 != NULL); out_type 0 = bf16,
  * 1 = fp32, 2 = fp16; optional input-row remap in_row = (r / rows_in) * rows_stride + row_off + r % rows_in and
  * output-row remap out_row = (r / rows_in) * orows_stride + orow_off + r % rows_in (orows_stride > 0).
- * Replaces nn.LayerNorm at iggt/layers/block.py:84,87, iggt/layers/vision_transformer.py:274 and
- * iggt/heads/dpt_head.py:232. */
+ * Replaces nn.LayerNorm at iggt/layers/block.py:84,87, iggt/layers/vision_transformer.py:274,
+ * iggt/heads/dpt_head.py:232 and the norms of iggt/heads/window_sa.py (HAB / OCAB / wrapper norms). */
 int iggt_layernorm_f32(const float* x0, long ld0, const float* x1, long ld1, const float* w,
                        const float* b, void* out, long ldo, int out_type, int rows, int C,
                        float eps, int rows_in, int rows_stride, int row_off, int orows_stride, int orow_off,

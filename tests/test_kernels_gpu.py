@@ -311,3 +311,31 @@ def test_head_tail(C, Cout, act, conf_act):
     rp, rc = activate_head(lin.permute(0, 3, 1, 2), activation=act, conf_activation=conf_act)
     assert pts.shape == rp.shape and conf.shape == rc.shape
     assert _relerr(pts, rp)[0] < 2e-6 and _relerr(conf, rc)[0] < 2e-6
+
+
+def test_tokenops_layernorm_and_linear(C):
+    """Part-head token ops on HIP: LayerNorm (incl. the 32-lane C = 128 kernel) and Linear as a split-bf16 1x1 GEMM with
+    fused GELU / residual, against fp64."""
+    import torch.nn as nn
+
+    from iggt_official_amd.heads import tokenops as tk
+
+    for Cdim in (128, 256):
+        x = _rand((3, 77, Cdim), 90 + Cdim, 2.0) + 0.3
+        norm = nn.LayerNorm(Cdim).cuda()
+        with torch.no_grad():
+            norm.weight.copy_(_rand((Cdim,), 91) * 0.1 + 1)
+            norm.bias.copy_(_rand((Cdim,), 92, 0.1))
+        y = tk.layer_norm(norm, x)
+        ref = torch.nn.functional.layer_norm(x.double(), (Cdim,), norm.weight.double(), norm.bias.double(), norm.eps)
+        assert y.shape == x.shape and _relerr(y, ref)[0] < 1e-5
+    lin1, lin2 = nn.Linear(128, 512).cuda(), nn.Linear(512, 128).cuda()
+    x = _rand((2, 301, 128), 93)
+    with torch.no_grad():
+        h = tk.linear(lin1, x, act=3)
+        y = tk.linear(lin2, h, res=x)
+        ref_h = torch.nn.functional.gelu(torch.nn.functional.linear(x.double(), lin1.weight.double(), lin1.bias.double()))
+        ref = x.double() + torch.nn.functional.linear(ref_h, lin2.weight.double(), lin2.bias.double())
+    assert _relerr(h, ref_h)[0] < 2e-5 and _relerr(y, ref)[0] < 2e-5
+    with pytest.raises(C.HipExtensionError):
+        tk.linear(lin1, x.cpu())
