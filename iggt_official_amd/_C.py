@@ -12,7 +12,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -44,6 +44,8 @@ _SIGNATURES = {
     "iggt_bias_correct_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
     "iggt_head_tail_f32": [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int,
                            _c_int, _c_void_p],
+    "iggt_window_attn_f32": [_c_void_p, _c_long, _c_int, _c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long,
+                             _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_void_p],
     "iggt_conv2d_nhwc_f32": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                              _c_int]
                             + [_c_int] * 24 + [_c_void_p],
@@ -235,6 +237,32 @@ def head_tail(x, w, b, activation, conf_activation):
                                    _stream())
     _check(rc, "iggt_head_tail_f32")
     return pts, conf
+
+
+def window_attn(q, k, v, out, heads, head_dim, scale, *, q_windows=False, ow=8, pad=0, bias=None):
+    """Part-head window attention (include/iggt_hip.h).  k, v, out: NHWC fp32 views [b,h,w,>=head_dim*heads] (channel
+    slices allowed, unit channel stride); q: the same kind of map, or window-major [nW,64,C] when q_windows."""
+    _dev(q, k, v, out, bias)
+    for t in (q, k, v, out):
+        assert t.dtype == torch.float32 and t.stride(-1) == 1
+    b, h, w = k.shape[:3]
+
+    def ld(t):   # NHWC view of a contiguous [b,h,w,ld] buffer: pixel stride
+        assert t.stride(1) == t.stride(2) * t.shape[2] and t.stride(0) == t.stride(1) * t.shape[1]
+        return t.stride(2)
+
+    if q_windows:
+        assert q.dim() == 3 and q.shape[1] == 64 and q.is_contiguous() and q.shape[0] == b * (h // 8) * (w // 8)
+        q_ld = q.stride(1)
+    else:
+        q_ld = ld(q)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.shape == (heads, ow * ow, 64)
+    rc = load().iggt_window_attn_f32(q.data_ptr(), q_ld, int(q_windows), k.data_ptr(), ld(k), v.data_ptr(), ld(v),
+                                     out.data_ptr(), ld(out), _ptr(bias), b, h, w, heads, head_dim, ow, pad,
+                                     float(scale), _stream())
+    _check(rc, "iggt_window_attn_f32")
+    return out
 
 
 def write_special_tokens(dst, src0, src1, S, nrows, row_off, first_view_is_zero):

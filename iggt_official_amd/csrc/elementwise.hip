@@ -418,6 +418,95 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const TailParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Window attention of the part head, head dim 32 (HAB) or 64 (OCAB), fp32 (the reference runs these stages in fp32):
+//   HAB  (iggt/heads/window_sa.py:163-227 + heads/block.py:120-150): 8x8 windows, queries = keys = the window;
+//   OCAB (window_sa.py:229-319): 8x8 query windows, 12x12 overlapping key/value windows (stride 8, zero padding 2:
+//        out-of-image keys are ZERO VECTORS that still take part in the softmax with score = bias, as nn.Unfold
+//        pads with zeros), learned relative-position bias.
+// One wave per (window, head), lane = query token: the query row (D floats) and the output accumulator live in
+// registers; key / value rows are wave-uniform addresses (scalar loads), online softmax per lane.  q comes either
+// from an NHWC map (q_mode 0) or from a window-major [nW][64][ld] tensor (q_mode 1: OCAB's scrambled query windows);
+// k, v are NHWC maps read in place (no window_partition / Unfold copies), the output goes straight into an NHWC map.
+struct WinAttnParams {
+    const float* q; long q_ld; int q_mode;
+    const float* k; long k_ld;
+    const float* v; long v_ld;
+    float* o; long o_ld;
+    const float* bias;   // [heads][ow*ow][64] or null
+    int b, h, w, heads, ow, pad;
+    float scale;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void window_attn_kernel(const WinAttnParams p) {
+    const int lane = threadIdx.x & 63;
+    const int head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwx = p.w >> 3, nwy = p.h >> 3;
+    const int win = blockIdx.x;
+    const int bi = win / (nwy * nwx), wrem = win - bi * (nwy * nwx);
+    const int wy = wrem / nwx, wx = wrem - wy * nwx;
+    const int qy = lane >> 3, qx = lane & 7;
+    const long pix = ((long)bi * p.h + wy * 8 + qy) * p.w + wx * 8 + qx;
+    const float* qp = p.q_mode ? p.q + ((long)win * 64 + lane) * p.q_ld + head * D : p.q + pix * p.q_ld + head * D;
+    float q[D], o[D];
+#pragma unroll
+    for (int c = 0; c < D / 4; ++c) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(qp + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            q[4 * c + e] = t[e] * p.scale;
+            o[4 * c + e] = 0.f;
+        }
+    }
+    float m = -INFINITY, l = 0.f;
+    const int nk = p.ow * p.ow;
+    const float* bias = p.bias ? p.bias + (long)head * nk * 64 + lane : nullptr;
+    for (int j = 0; j < nk; ++j) {
+        const int ky = j / p.ow, kx = j - ky * p.ow;
+        const int py = wy * 8 - p.pad + ky, px = wx * 8 - p.pad + kx;   // wave-uniform
+        const bool inb = py >= 0 && py < p.h && px >= 0 && px < p.w;
+        float sc = bias ? bias[(long)j * 64] : 0.f;
+        const long kpix = ((long)bi * p.h + (inb ? py : 0)) * p.w + (inb ? px : 0);
+        if (inb) {
+            const float* __restrict__ kr = p.k + kpix * p.k_ld + head * D;
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; c += 4) {
+                d0 = fmaf(q[c], kr[c], d0);
+                d1 = fmaf(q[c + 1], kr[c + 1], d1);
+                d2 = fmaf(q[c + 2], kr[c + 2], d2);
+                d3 = fmaf(q[c + 3], kr[c + 3], d3);
+            }
+            sc += (d0 + d1) + (d2 + d3);
+        }
+        const float m_new = fmaxf(m, sc);
+        if (__any(m_new > m)) {   // some query's running max moved: rescale (lanes whose max did not move get corr = 1)
+            const float corr = __expf(m - m_new);
+            m = m_new;
+            l *= corr;
+#pragma unroll
+            for (int c = 0; c < D; ++c) o[c] *= corr;
+        }
+        const float pj = __expf(sc - m);
+        l += pj;
+        if (inb) {
+            const float* __restrict__ vr = p.v + kpix * p.v_ld + head * D;
+#pragma unroll
+            for (int c = 0; c < D; ++c) o[c] = fmaf(pj, vr[c], o[c]);
+        }
+    }
+    const float inv = 1.0f / l;
+    float* op = p.o + pix * p.o_ld + head * D;
+#pragma unroll
+    for (int c = 0; c < D / 4; ++c) {
+        f32x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = o[4 * c + e] * inv;
+        *reinterpret_cast<f32x4*>(op + 4 * c) = t;
+    }
+}
+
 }  // namespace
 
 extern "C" int iggt_layernorm_f32(const float* x0, long ld0, const float* x1, long ld1, const float* w,
@@ -555,6 +644,24 @@ extern "C" int iggt_head_tail_f32(const float* x, long ldx, const float* w, cons
     long blocks = (npix + 31) / 32;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(head_tail_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int iggt_window_attn_f32(const float* q, long q_ld, int q_mode, const float* k, long k_ld, const float* v,
+                                    long v_ld, float* o, long o_ld, const float* bias, int b, int h, int w, int heads,
+                                    int head_dim, int ow, int pad, float scale, void* stream) {
+    if (b <= 0 || h <= 0 || w <= 0 || (h % 8) || (w % 8) || heads < 1 || heads > 4 || ow < 1 || pad < 0) return -1;
+    if (head_dim != 32 && head_dim != 64) return -3;
+    if ((q_ld % 4) || (k_ld % 4) || (v_ld % 4) || (o_ld % 4)) return -2;
+    WinAttnParams p;
+    p.q = q; p.q_ld = q_ld; p.q_mode = q_mode; p.k = k; p.k_ld = k_ld; p.v = v; p.v_ld = v_ld; p.o = o; p.o_ld = o_ld;
+    p.bias = bias; p.b = b; p.h = h; p.w = w; p.heads = heads; p.ow = ow; p.pad = pad; p.scale = scale;
+    const long nwin = (long)b * (h / 8) * (w / 8);
+    if (head_dim == 32)
+        hipLaunchKernelGGL(window_attn_kernel<32>, dim3((unsigned)nwin), dim3(64 * heads), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(window_attn_kernel<64>, dim3((unsigned)nwin), dim3(64 * heads), 0, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
     return 0;
 }

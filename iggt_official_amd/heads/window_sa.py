@@ -15,13 +15,15 @@ Two reference behaviours are reproduced on purpose because trained weights depen
 Execution: NHWC fp32; every 3x3 convolution (CAB, conv_after_body, conv_before_upsample, conv_last) runs on
 the implicit-GEMM MFMA kernel (csrc/conv_igemm.hip; CAB's 42-channel bottleneck is zero-padded to 64); LayerNorms
 and Linear layers (q/k/v/proj, MLPs with fused GELU and residual adds) run on HIP kernels through heads/tokenops.py;
-only the head-dim-32 window attention cores (8x8 queries, 64 / 144 keys) and the window gather/scatter copies are
-PyTorch-ROCm fp32 ops.
+the window attention cores (8x8 queries; 64 keys, d = 32 in HAB; 144 keys, d = 64 and a relative-position bias in
+OCAB) run on `iggt_window_attn_f32`, which gathers windows straight from the NHWC maps (no partition / Unfold copies).  Left on
+PyTorch-ROCm ops: OCAB's query scramble (one permuted copy), CAB's squeeze-excite Linears, the residual adds.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import _C
 from . import convops as co
 from . import tokenops as tk
 from .block import MemEffAttention
@@ -127,10 +129,17 @@ class HAB(nn.Module):
         h, w = x_size
         b, _, c = x.shape
         ws = self.window_size
+        if ws != 8 or self.attn.head_dim not in (32, 64):
+            raise _C.HipExtensionError("HIP window attention is built for 8x8 windows and head dim 32 / 64")
         y = tk.layer_norm(self.norm1, x).view(b, h, w, c)
         conv_x = self.conv_block.forward_nhwc(y.contiguous()).reshape(b, h * w, c)
-        win = window_partition(y, ws).view(-1, ws * ws, c)
-        att = window_reverse(self.attn(win).view(-1, ws, ws, c), ws, h, w).view(b, h * w, c)
+        # per-token Linear layers commute with the window partition: qkv / proj run on the whole map and the attention
+        # kernel gathers the 8x8 windows itself (no window_partition / window_reverse copies)
+        qkv = tk.linear(self.attn.qkv, y)                                                  # [b, h, w, 3c]
+        o = torch.empty(b, h, w, c, dtype=torch.float32, device=x.device)
+        _C.window_attn(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], o, self.attn.num_heads, self.attn.head_dim,
+                       self.attn.scale)
+        att = tk.linear(self.attn.proj, o).view(b, h * w, c)
         x = x + att + conv_x * self.conv_scale
         return self.mlp(tk.layer_norm(self.norm2, x), res=x)
 
@@ -168,21 +177,21 @@ class OCAB(nn.Module):
         ws, ow, nh = self.window_size, self.overlap_win_size, self.num_heads
         d = c // nh
         shortcut = x
+        if ws != 8 or d not in (32, 64):
+            raise _C.HipExtensionError("HIP window attention is built for 8x8 windows and head dim 32 / 64")
         q = tk.linear(self.q, tk.layer_norm(self.norm1, x)).view(b, h, w, c)
-        kk = tk.linear(self.k, tk.layer_norm(self.norm1, k)).view(b, h, w, c).permute(0, 3, 1, 2)
-        vv = tk.linear(self.v, tk.layer_norm(self.norm1, v)).view(b, h, w, c).permute(0, 3, 1, 2)
-        qw = _ocab_query_windows(q, ws)                                              # [b*nw, 64, c]
+        kk = tk.linear(self.k, tk.layer_norm(self.norm1, k)).view(b, h, w, c)
+        vv = tk.linear(self.v, tk.layer_norm(self.norm1, v)).view(b, h, w, c)
+        qw = _ocab_query_windows(q, ws).contiguous()                                 # [b*nw, 64, c] (layout quirk D.4)
         pad = (ow - ws) // 2
-        kv = F.unfold(torch.cat((kk, vv), 1), kernel_size=(ow, ow), stride=ws, padding=pad)  # [b, 2c*ow*ow, nw]
-        nw = kv.shape[-1]
-        kv = kv.view(b, 2, c, ow * ow, nw).permute(1, 0, 4, 3, 2).reshape(2, b * nw, ow * ow, c)
-        qh = qw.view(-1, ws * ws, nh, d).transpose(1, 2)
-        kh = kv[0].view(-1, ow * ow, nh, d).transpose(1, 2)
-        vh = kv[1].view(-1, ow * ow, nh, d).transpose(1, 2)
-        bias = self.relative_position_bias_table[rpi.reshape(-1)].view(ws * ws, ow * ow, nh).permute(2, 0, 1)
-        o = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=bias.unsqueeze(0).contiguous(), scale=self.scale)
-        o = o.transpose(1, 2).reshape(-1, ws, ws, c)
-        x = tk.linear(self.proj, window_reverse(o, ws, h, w).view(b, h * w, c), res=shortcut)
+        # bias[head][key][query]: the kernel's lanes are the queries
+        bias = self.relative_position_bias_table.detach().float()[rpi.reshape(-1)].view(ws * ws, ow * ow, nh)
+        bias = bias.permute(2, 1, 0).contiguous()
+        o = torch.empty(b, h, w, c, dtype=torch.float32, device=x.device)
+        # keys / values: 12x12 windows at stride 8 read in place from the maps (zero vectors outside the image, like
+        # nn.Unfold's padding); output written at the regular window positions (= window_reverse)
+        _C.window_attn(qw, kk, vv, o, nh, d, self.scale, q_windows=True, ow=ow, pad=pad, bias=bias)
+        x = tk.linear(self.proj, o.view(b, h * w, c), res=shortcut)
         return self.mlp(tk.layer_norm(self.norm2, x), res=x)
 
 

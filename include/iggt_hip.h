@@ -95,6 +95,16 @@ int iggt_im2row_patch14(const float* img, void* out, int out_f16, int S, int H, 
 int iggt_head_tail_f32(const float* x, long ldx, const float* w, const float* b, float* pts, float* conf,
                        long npix, int Cout, int act, int conf_act, void* stream);
 
+/* Window attention of the part head, head dim 32 or 64, fp32: 8x8 query windows, ow x ow key/value windows at stride 8 with
+ * `pad` zero padding (ow = 8, pad = 0: HAB self-attention; ow = 12, pad = 2: OCAB), optional additive bias
+ * [heads][ow*ow][64].  q: NHWC map (q_mode 0) or window-major [nW][64][q_ld] (q_mode 1); k, v, o: NHWC maps
+ * [b][h][w][ld]; channel offsets are folded into the pointers; head hd uses channels [head_dim * hd, head_dim * (hd + 1)).
+ * Replaces window_partition + attention core + window_reverse (iggt/heads/window_sa.py:71-81,163-227) and
+ * Unfold + biased softmax attention of OCAB (window_sa.py:229-319). */
+int iggt_window_attn_f32(const float* q, long q_ld, int q_mode, const float* k, long k_ld, const float* v,
+                         long v_ld, float* o, long o_ld, const float* bias, int b, int h, int w, int heads,
+                         int head_dim, int ow, int pad, float scale, void* stream);
+
 /* Mean-input compensation of the 16-bit weight rounding (no counterpart in the reference, which is fp32 on the
  * CPU path this repository is checked against; see iggt_official_amd/precision.py):
  *   iggt_colmean_h16:      mu[k] = mean over rows 0, row_step, 2*row_step, ... of the 16-bit matrix x [rows][K]

@@ -339,3 +339,39 @@ def test_tokenops_layernorm_and_linear(C):
     assert _relerr(h, ref_h)[0] < 2e-5 and _relerr(y, ref)[0] < 2e-5
     with pytest.raises(C.HipExtensionError):
         tk.linear(lin1, x.cpu())
+
+
+@pytest.mark.parametrize("d", [32, 64])
+def test_window_attn(C, d):
+    """Part-head window attention kernel against the reference formulation (window_partition / nn.Unfold + softmax)."""
+    import torch.nn.functional as F
+
+    from iggt_official_amd.heads.window_sa import window_partition, window_reverse
+
+    b, h, w, nh = 2, 16, 24, 4
+    c = nh * d
+    scale = d ** -0.5
+    # (a) HAB: q, k, v slices of one [b,h,w,3c] map, 8x8 windows, no bias
+    qkv = _rand((b, h, w, 3 * c), 100, 1.0)
+    o = torch.full((b, h, w, c), float("nan"), device="cuda")
+    C.window_attn(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], o, nh, d, scale)
+    win = window_partition(qkv.double(), 8).view(-1, 64, 3, nh, d).permute(2, 0, 3, 1, 4)
+    ref = F.scaled_dot_product_attention(win[0], win[1], win[2], scale=scale)
+    ref = window_reverse(ref.transpose(1, 2).reshape(-1, 8, 8, c), 8, h, w)
+    assert _relerr(o, ref)[0] < 1e-5
+    # (b) OCAB: window-major queries, 12x12 zero-padded key/value windows, additive bias
+    ow, pad = 12, 2
+    nW = b * (h // 8) * (w // 8)
+    qw = _rand((nW, 64, c), 101, 1.0)
+    kk, vv = _rand((b, h, w, c), 102, 1.0), _rand((b, h, w, c), 103, 1.0)
+    bias = _rand((nh, 64, ow * ow), 104, 0.5)                      # [head][query][key] as the reference builds it
+    o = torch.full((b, h, w, c), float("nan"), device="cuda")
+    C.window_attn(qw, kk, vv, o, nh, d, scale, q_windows=True, ow=ow, pad=pad,
+                  bias=bias.permute(0, 2, 1).contiguous())
+    kv = F.unfold(torch.cat((kk, vv), -1).permute(0, 3, 1, 2).double(), kernel_size=(ow, ow), stride=8, padding=pad)
+    kv = kv.view(b, 2, c, ow * ow, -1).permute(1, 0, 4, 3, 2).reshape(2, nW, ow * ow, c)
+    qh = qw.double().view(nW, 64, nh, d).transpose(1, 2)
+    kh, vh = (t.view(nW, ow * ow, nh, d).transpose(1, 2) for t in (kv[0], kv[1]))
+    ref = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=bias.double().unsqueeze(0), scale=scale)
+    ref = window_reverse(ref.transpose(1, 2).reshape(-1, 8, 8, c), 8, h, w)
+    assert _relerr(o, ref)[0] < 1e-5
