@@ -145,3 +145,41 @@ def test_single_view_matches_oracle():
         e = errors(pred[k], ref[k])
         assert e[1] < 1e-3, (k, e)
     assert errors(torch.stack(pred["pose_enc"], 0), torch.stack(ref["pose_enc"], 0))[1] < 1e-3
+
+
+def test_vggt_and_module_api_surface():
+    """VGGT (geometry-only model of the reference, vggt.py:26-95), Aggregator(keep_layers='all') and the reference
+    Block.forward signature run on the same kernels and agree with the paths the fixtures pin."""
+    from iggt.models.vggt import VGGT
+    from oracle import weights
+
+    model = build_gpu_model("stress", 0)
+    images = weights.make_images(2, 56, 56, seed=3, device="cuda")
+    ref = model(images)
+    with torch.device("cuda"):
+        vggt = VGGT().eval()
+    missing, unexpected = vggt.load_state_dict(model.state_dict(), strict=False)
+    assert not missing and all(u.startswith(("part_", "track_head")) for u in unexpected)
+    out = vggt(images)
+    assert set(out) == {"pose_enc", "depth", "depth_conf", "world_points", "world_points_conf", "images"}
+    for k in ("depth", "depth_conf", "world_points", "world_points_conf"):
+        assert torch.equal(out[k], ref[k]), k            # same kernels, same arithmetic
+    # all 24 aggregator outputs on request; the four consumed ones are unchanged
+    agg = model.aggregator
+    default, psi = agg(images[None])
+    old = agg.keep_layers
+    try:
+        agg.keep_layers = "all"
+        full, _ = agg(images[None])
+    finally:
+        agg.keep_layers = old
+    assert psi == 5 and all(t is not None and t.shape == (1, 2, 21, 2048) for t in full)
+    assert [i for i, t in enumerate(default) if t is not None] == [4, 11, 17, 23]
+    for i in (4, 11, 17, 23):
+        assert torch.equal(full[i], default[i])
+    # reference Block.forward(x) signature on a DINOv2 block (no RoPE): new tensor, input untouched
+    blk = agg.patch_embed.blocks[0]
+    x = torch.randn(2, 21, 1024, device="cuda")
+    x0 = x.clone()
+    y = blk(x)
+    assert y.shape == x.shape and torch.equal(x, x0) and torch.isfinite(y).all() and not torch.equal(y, x)
