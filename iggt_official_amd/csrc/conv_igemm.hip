@@ -28,6 +28,8 @@
 // Tiling: 128 x (32*WN*WAVES_N) output tile, BK = 32, 256 threads; LDS images [rows][32] bf16 with
 // the 16-B slot XOR ((row >> 2) & 3) (conflict-free ds_read_b128 for 64-byte rows), double-buffered,
 // register-staged two K-steps ahead (two register sets).
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/iggt_hip.h"
 
@@ -63,15 +65,26 @@ IGGT_DEVINL int slot_swz(int row, int slot) {
     return row * 64 + (((slot ^ (row >> 2) ^ ((row >> 1) & 1)) & 3) << 4);
 }
 
+// Tile geometry of one instantiation (shared by the kernel and its launcher).
 template <int PREC, int WM, int WN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
-    constexpr int BM = 32 * WM * WAVES_M;
-    constexpr int BN = 32 * WN * WAVES_N;
-    static_assert(BM == 128 && WAVES_M * WAVES_N == 4, "256-thread tile");
-    constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64;
-    constexpr int STAGE = PREC * 0 + (PREC == 3 ? 2 : 1) * (A_BYTES + W_BYTES);
-    constexpr int SMEM = (2 * STAGE > BM * BN * 4) ? 2 * STAGE : BM * BN * 4;  // stage ring, reused by the epilogue
-    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+struct ConvTile {
+    static constexpr int THREADS = 64 * WAVES_M * WAVES_N;
+    static constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
+    static constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64;
+    static constexpr int STAGE = (PREC == 3 ? 2 : 1) * (A_BYTES + W_BYTES);
+    // the epilogue transposes the tile through the (then idle) stage ring, at most 128 KiB (= 128 rows of 256) a pass
+    static constexpr int EPI_ROWS = (BM * BN * 4 > 131072) ? BM / 2 : BM;
+    static constexpr int SMEM = (2 * STAGE > EPI_ROWS * BN * 4) ? 2 * STAGE : EPI_ROWS * BN * 4;
+};
+
+template <int PREC, int WM, int WN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(const ConvParams p) {
+    using T = ConvTile<PREC, WM, WN, WAVES_M, WAVES_N>;
+    constexpr int THREADS = T::THREADS, BM = T::BM, BN = T::BN;
+    static_assert(BM == THREADS / 2, "A loader: two threads per tile row");
+    static_assert(T::EPI_ROWS == BM || WAVES_M == 2, "two-pass epilogue: one wave row per pass");
+    constexpr int A_BYTES = T::A_BYTES, W_BYTES = T::W_BYTES, STAGE = T::STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -91,8 +104,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     const int a_oy = a_rem / p.Wo, a_ox = a_rem - a_oy * p.Wo;
     const int iy0 = a_oy * p.stride - p.pad_y, ix0 = a_ox * p.stride - p.pad_x;
     const float* a_base = p.x + ((long)a_img * p.Hi * p.Wi) * p.ldx + a_half * 16;
-    // ---- W loader: rows of 64 B (32 bf16); 256 threads x 16 B = 64 rows per pass ---------------------
-    constexpr int W_PASSES = BN / 64 > 0 ? BN / 64 : 1;
+    // ---- W loader: rows of 64 B (32 bf16); THREADS x 16 B = THREADS/4 rows per pass ------------------
+    constexpr int RPP = THREADS / 4;
+    constexpr int W_PASSES = (BN + RPP - 1) / RPP;
     const int w_row = tid >> 2, w_piece = tid & 3;  // 4 x 16 B per row
     const long Ktot = (long)p.KH * p.KW * p.Cin;
     const int chunks_per_tap = p.Cin / BK;
@@ -113,8 +127,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     const bf16_t* w_ptr_lo[W_PASSES];
 #pragma unroll
     for (int q = 0; q < W_PASSES; ++q) {
-        int r = n0 + w_row + 64 * q;
-        if (BN < 64 && w_row >= BN) r = n0;  // BN == 32: upper half of the threads duplicate row 0
+        int r = n0 + w_row + RPP * q;
+        if (w_row + RPP * q >= BN) r = n0;  // BN < rows per pass: the surplus threads duplicate row 0
         r = r < p.Cout ? r : p.Cout - 1;
         w_ptr_hi[q] = p.w_hi + (long)r * Ktot + w_piece * 8;
         w_ptr_lo[q] = (PREC == 3) ? p.w_lo + (long)r * Ktot + w_piece * 8 : nullptr;
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         }
 #pragma unroll
         for (int q = 0; q < W_PASSES; ++q) {
-            const int r = w_row + 64 * q;
+            const int r = w_row + RPP * q;
             if (r < BN) {
                 const int off = slot_swz(r, w_piece);
                 *reinterpret_cast<u32x4*>(sWh + off) = R.rwh[q];
@@ -203,6 +217,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         const char* sWl = sAl + A_BYTES;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
+            if constexpr (WM >= 4) {   // big tile: fragments of one A row-block at a time (register budget)
+                bf16x8 bh[WN], bl[WN];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int off = slot_swz((wn * WN + j) * 32 + frow, 2 * kc + fhalf);
+                    bh[j] = *reinterpret_cast<const bf16x8*>(sWh + off);
+                    if (PREC == 3) bl[j] = *reinterpret_cast<const bf16x8*>(sWl + off);
+                }
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    const int off = slot_swz((wm * WM + i) * 32 + frow, 2 * kc + fhalf);
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(sAh + off);
+                    bf16x8 al = ah;
+                    if (PREC == 3) al = *reinterpret_cast<const bf16x8*>(sAl + off);
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        if (PREC == 3) {  // small terms first
+                            acc[i][j] = mfma32(al, bh[j], acc[i][j]);
+                            acc[i][j] = mfma32(ah, bl[j], acc[i][j]);
+                        }
+                        acc[i][j] = mfma32(ah, bh[j], acc[i][j]);
+                    }
+                }
+                continue;
+            }
             bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
@@ -228,22 +267,38 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
                 }
         }
     };
-    gload(R0);            // chunk 0
-    if (KT > 1) gload(R1);  // chunk 1
-    swrite(0, R0);
-    __syncthreads();
-    for (int kt = 0; kt < KT; kt += 2) {
-        // even step: chunk kt in LDS buffer 0, chunk kt+1 in R1, request chunk kt+2 into R0
-        if (kt + 2 < KT) gload(R0);
-        compute(0);
-        if (kt + 1 < KT) swrite(1, R1);
+    // 256-thread tiles prefetch two chunks ahead (two register sets); the 512-thread 256x256 tile has no registers to
+    // spare (128 accumulators + 48 fragment registers) and prefetches one chunk ahead.
+    constexpr bool TWO_AHEAD = THREADS == 256;
+    if constexpr (TWO_AHEAD) {
+        gload(R0);            // chunk 0
+        if (KT > 1) gload(R1);  // chunk 1
+        swrite(0, R0);
         __syncthreads();
-        if (kt + 1 >= KT) break;
-        // odd step: chunk kt+1 in buffer 1, chunk kt+2 in R0, request chunk kt+3 into R1
-        if (kt + 3 < KT) gload(R1);
-        compute(1);
-        if (kt + 2 < KT) swrite(0, R0);
+        for (int kt = 0; kt < KT; kt += 2) {
+            // even step: chunk kt in LDS buffer 0, chunk kt+1 in R1, request chunk kt+2 into R0
+            if (kt + 2 < KT) gload(R0);
+            compute(0);
+            if (kt + 1 < KT) swrite(1, R1);
+            __syncthreads();
+            if (kt + 1 >= KT) break;
+            // odd step: chunk kt+1 in buffer 1, chunk kt+2 in R0, request chunk kt+3 into R1
+            if (kt + 3 < KT) gload(R1);
+            compute(1);
+            if (kt + 2 < KT) swrite(0, R0);
+            __syncthreads();
+        }
+
+    } else {
+        gload(R0);
+        swrite(0, R0);
         __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) gload(R0);
+            compute(kt & 1);
+            if (kt + 1 < KT) swrite((kt + 1) & 1, R0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue through LDS ------------------------------------------------------------------
@@ -252,19 +307,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     // transposed through the (now idle) stage buffers and leaves as 16-byte accesses, a wave covering whole
     // contiguous output rows; bias / activation / residuals are applied on float4s.
     float* stile = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stile[((wm * WM + i) * 32 + mfma32_row(r, lane)) * BN + (wn * WN + j) * 32 + (lane & 31)] = acc[i][j][r];
-    __syncthreads();
+    constexpr int EPI_ROWS = T::EPI_ROWS, NPASS = BM / EPI_ROWS;
     constexpr int C4 = BN / 4;
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; ++pass) {
+    if (NPASS == 1 || wm == pass) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stile[((wm * WM + i) * 32 + mfma32_row(r, lane) - pass * EPI_ROWS) * BN + (wn * WN + j) * 32 +
+                          (lane & 31)] = acc[i][j][r];
+    }
+    __syncthreads();
 #pragma unroll 4
-    for (int idx = tid; idx < BM * C4; idx += 256) {
+    for (int idx = tid; idx < EPI_ROWS * C4; idx += THREADS) {
         const int row = idx / C4, c4 = idx - row * C4;
-        const long m = m0 + row;
+        const long m = m0 + pass * EPI_ROWS + row;
         const int n = n0 + c4 * 4;
         if (m >= p.M || n >= p.Cout) continue;
         const int img = (int)(m / hw);
@@ -320,16 +381,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             }
         }
     }
+    if (NPASS > 1) __syncthreads();
+    }
 }
 
 template <int PREC, int WM, int WN, int WAVES_M, int WAVES_N>
-void launch(const ConvParams& p, hipStream_t st) {
-    constexpr int BN = 32 * WN * WAVES_N;
+int launch(const ConvParams& p, hipStream_t st) {
+    using T = ConvTile<PREC, WM, WN, WAVES_M, WAVES_N>;
+    static bool attr_set = false;
+    if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in (one-time, like the GEMM kernels)
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<PREC, WM, WN, WAVES_M, WAVES_N>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
     ConvParams q = p;
-    q.tiles_n = (p.Cout + BN - 1) / BN;
-    const long tiles_m = (p.M + 127) / 128;
+    q.tiles_n = (p.Cout + T::BN - 1) / T::BN;
+    const long tiles_m = (p.M + T::BM - 1) / T::BM;
     hipLaunchKernelGGL((conv_igemm_kernel<PREC, WM, WN, WAVES_M, WAVES_N>), dim3((unsigned)(tiles_m * q.tiles_n)),
-                       dim3(256), 0, st, q);
+                       dim3(T::THREADS), T::SMEM, st, q);
+    return 0;
 }
 
 }  // namespace
@@ -357,15 +428,30 @@ extern "C" int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, c
     p.M = (long)Nimg * Ho * Wo;
     p.tiles_n = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (prec == 3) {
-        if (Cout > 64) launch<3, 2, 2, 2, 2>(p, st);
-        else if (Cout > 32) launch<3, 1, 2, 4, 1>(p, st);
-        else launch<3, 1, 1, 4, 1>(p, st);
-    } else {
-        if (Cout > 64) launch<1, 2, 2, 2, 2>(p, st);
-        else if (Cout > 32) launch<1, 1, 2, 4, 1>(p, st);
-        else launch<1, 1, 1, 4, 1>(p, st);
+    // 256x256 tile (8 waves, one workgroup per CU): every split activation is used for 256 output channels instead of
+    // 128 -- half the loader work (loads, hi/lo split, LDS writes) per MFMA.  Only when the grid still fills the chip.
+    static int big = -1, cus = 256;
+    if (big < 0) {
+        const char* e = getenv("IGGT_CONV_TILE256");
+        big = (e && e[0] == '0') ? 0 : 1;
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
     }
+    const bool use_big = big && prec == 3 && (Cout % 256) == 0 && ((p.M + 255) / 256) * (Cout / 256) >= 2L * cus;
+    int rc;
+    if (prec == 3) {
+        if (use_big) rc = launch<3, 4, 2, 2, 4>(p, st);
+        else if (Cout > 64) rc = launch<3, 2, 2, 2, 2>(p, st);
+        else if (Cout > 32) rc = launch<3, 1, 2, 4, 1>(p, st);
+        else rc = launch<3, 1, 1, 4, 1>(p, st);
+    } else {
+        if (Cout > 64) rc = launch<1, 2, 2, 2, 2>(p, st);
+        else if (Cout > 32) rc = launch<1, 1, 2, 4, 1>(p, st);
+        else rc = launch<1, 1, 1, 4, 1>(p, st);
+    }
+    if (rc != 0) return rc;
     IGGT_CHECK_LAUNCH();
     return 0;
 }

@@ -113,3 +113,35 @@ def test_bilinear_align_corners(hi, ho):
     add = torch.cat([xr.t()[None, :, None, :].expand(1, 64, ho[0], ho[1]),
                      yr.t()[None, :, :, None].expand(1, 64, ho[0], ho[1])], 1)
     assert _err(y2.permute(0, 3, 1, 2), ref + add)[0] < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,k,stride", [(256, 256, 3, 1), (64, 512, 1, 1), (128, 256, 3, 2)])
+def test_conv_big_tile_path(cin, cout, k, stride):
+    """Shapes large enough for the 8-wave 256x256 tile (Cout % 256 == 0, >= 2 x CUs tiles): ragged last row tile,
+    fused ReLU-on-load / residuals / activation, two-pass LDS epilogue.  fp64 reference on a pixel sample (the full
+    fp64 convolution of 2e5 pixels is slow); every pixel is checked for finiteness."""
+    from iggt_official_amd.heads import convops as co
+
+    N, H, W = 6, 150, 151            # 135 900 pixels at stride 1: 531 row tiles (the last one ragged)
+    pad = k // 2
+    conv = nn.Conv2d(cin, cout, k, stride, pad).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(_mk(conv.weight.shape, 21, (cin * k * k) ** -0.5))
+        conv.bias.copy_(_mk(conv.bias.shape, 22, 0.1))
+    x = _mk((N, H, W, cin), 23)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = _mk((N, Ho, Wo, cout), 24)
+    y = co.run(co.pack_conv2d(conv), x, relu_in=True, res=res, relu_res=True, act=0)
+    assert torch.isfinite(y).all() and y.shape == (N, Ho, Wo, cout)
+    # reference on image 0's top rows and the last image's bottom rows (covers the first and the ragged last tile)
+    for img, rows in ((0, slice(0, 12)), (N - 1, slice(Ho - 12, Ho))):
+        r0 = rows.start * stride
+        xin = x[img:img + 1, max(r0 - pad, 0):min((rows.stop - 1) * stride + k - pad, H)]
+        top_pad = pad if r0 - pad < 0 else 0
+        bot_pad = pad if (rows.stop - 1) * stride + k - pad > H else 0
+        xd = F.pad(F.relu(xin.permute(0, 3, 1, 2).double()), (pad, pad, top_pad, bot_pad))
+        ref = F.conv2d(xd, conv.weight.double(), conv.bias.double(), stride, 0)
+        ref = ref + F.relu(res[img:img + 1, rows].permute(0, 3, 1, 2).double())
+        got = y[img:img + 1, rows].permute(0, 3, 1, 2)
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        assert _err(got, ref)[0] < 2e-5
