@@ -145,3 +145,18 @@ def test_conv_big_tile_path(cin, cout, k, stride):
         got = y[img:img + 1, rows].permute(0, 3, 1, 2)
         assert got.shape == ref.shape, (got.shape, ref.shape)
         assert _err(got, ref)[0] < 2e-5
+
+
+def test_conv_transpose_big_tile_path():
+    """ConvTranspose2d(k = s = 4) of the DPT resize stage at the size of a 32-view pass: the GEMM has 4096 output columns
+    (pixel-shuffle scatter epilogue) and enough row tiles for the 256x256 tile."""
+    from iggt_official_amd.heads import convops as co
+
+    s = 4
+    ct = nn.ConvTranspose2d(256, 256, s, s, 0).cuda()
+    x = _mk((32, 37, 37, 256), 31)
+    y = co.run(co.pack_convT_kernel_eq_stride(ct), x)
+    assert y.shape == (32, 37 * s, 37 * s, 256) and torch.isfinite(y).all()
+    for img in (0, 31):
+        ref = F.conv_transpose2d(x[img:img + 1].permute(0, 3, 1, 2).double(), ct.weight.double(), ct.bias.double(), s, 0)
+        assert _err(y[img:img + 1].permute(0, 3, 1, 2), ref)[0] < 2e-5
