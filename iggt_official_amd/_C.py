@@ -12,7 +12,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -46,6 +46,8 @@ _SIGNATURES = {
                            _c_int, _c_void_p],
     "iggt_window_attn_f32": [_c_void_p, _c_long, _c_int, _c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long,
                              _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_void_p],
+    "iggt_dpt_tail_f32": [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                          _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
     "iggt_conv2d_nhwc_f32": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                              _c_int]
                             + [_c_int] * 24 + [_c_void_p],
@@ -263,6 +265,27 @@ def window_attn(q, k, v, out, heads, head_dim, scale, *, q_windows=False, ow=8, 
                                      float(scale), _stream())
     _check(rc, "iggt_window_attn_f32")
     return out
+
+
+def dpt_tail(x, size, xpart, ypart, w_hi, w_lo, b1, w2, b2, activation, conf_activation):
+    """x NHWC fp32 [N,Hi,Wi,128] -> (pts [N,Ho,Wo,Cout-1], conf [N,Ho,Wo]): upsample + position map + conv3x3 + ReLU +
+    conv1x1 + activate_head in one kernel (include/iggt_hip.h)."""
+    _dev(x, xpart, ypart, w_hi, w_lo, b1, w2, b2)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == 128
+    N, Hi, Wi, _ = x.shape
+    Ho, Wo = size
+    Cout = w2.shape[0]
+    assert w_hi.dtype == torch.bfloat16 and w_hi.shape == (32, 9 * 128) and w_hi.is_contiguous() and w_lo.is_contiguous()
+    assert w2.shape == (Cout, 32) and w2.dtype == torch.float32 and w2.is_contiguous()
+    if xpart is not None:
+        assert xpart.shape == (Wo, 64) and ypart.shape == (Ho, 64) and xpart.is_contiguous() and ypart.is_contiguous()
+    pts = torch.empty(N, Ho, Wo, Cout - 1, dtype=torch.float32, device=x.device)
+    conf = torch.empty(N, Ho, Wo, dtype=torch.float32, device=x.device)
+    rc = load().iggt_dpt_tail_f32(x.data_ptr(), N, Hi, Wi, Ho, Wo, _ptr(xpart), _ptr(ypart), w_hi.data_ptr(),
+                                  w_lo.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), pts.data_ptr(),
+                                  conf.data_ptr(), Cout, HEAD_ACT[activation], CONF_ACT[conf_activation], _stream())
+    _check(rc, "iggt_dpt_tail_f32")
+    return pts, conf
 
 
 def write_special_tokens(dst, src0, src1, S, nrows, row_off, first_view_is_zero):

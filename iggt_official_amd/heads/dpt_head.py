@@ -18,6 +18,7 @@ Execution on the MI355X -- everything NHWC fp32 in HBM, all GEMM-shaped work on 
 Frames are independent in every head op, so `frames_chunk_size` only bounds
 memory; results do not depend on it (the reference's own chunked branch is broken for S > 12, App. D.1).
 """
+import os
 from typing import List
 
 import torch
@@ -103,6 +104,8 @@ def _make_scratch(in_shape, out_shape, groups=1, expand=False):
 # of HBM 32 frames fit easily (largest maps: 32 x 518^2 x 128 fp32 = 4.4 GB) and the larger launches fill the chip
 # better: 70.0 / 71.6 / 72.2 views/s at 8 / 16 / 32 (32 views @ 518^2).  Results do not depend on it.
 FRAMES_CHUNK = 32
+# One fused kernel for upsample -> conv3x3 -> ReLU -> conv1x1 -> activations (IGGT_FUSED_TAIL=0: the separate kernels)
+FUSED_TAIL = os.environ.get("IGGT_FUSED_TAIL", "1") != "0"
 
 
 class TokenProjector:
@@ -222,6 +225,24 @@ class DPTHead(nn.Module):
         maps = self._token_maps(tokens_list, psi, s0, s1, H, W)
         out, side = self.scratch_forward(maps)
         size = (int(gh * self.patch_size / self.down_ratio), int(gw * self.patch_size / self.down_ratio))
+        c2 = self.scratch.output_conv2
+        fused = (not self.for_tracker and FUSED_TAIL and out.shape[3] == 128 and c2[0].in_channels == 128
+                 and c2[0].out_channels == 32 and c2[0].kernel_size == (3, 3) and c2[0].padding == (1, 1)
+                 and c2[2].in_channels == 32 and 2 <= c2[2].out_channels <= 8
+                 and self.activation in ("linear", "exp", "relu", "inv_log", "sigmoid")
+                 and self.conf_activation in _C.CONF_ACT)
+        if fused:
+            # upsample + position map + conv3x3 + ReLU + conv1x1 + activate_head in ONE kernel (csrc/dpt_tail.hip):
+            # the full-resolution 128- and 32-channel maps never exist in HBM
+            xr, yr = pos_embed_rows(128, size[0], size[1], W, H, out.device) if self.pos_embed else (None, None)
+            pc = self._conv("oc2_0", c2[0])
+            b1 = pc.bias if pc.bias is not None else torch.zeros(32, dtype=torch.float32, device=out.device)
+            preds, conf = _C.dpt_tail(out.contiguous(), size, xr, yr, pc.w_hi, pc.w_lo, b1,
+                                      c2[2].weight.detach().float().reshape(c2[2].out_channels, 32).contiguous(),
+                                      c2[2].bias.detach().float().contiguous(), self.activation, self.conf_activation)
+            preds = preds.reshape(1, S, *preds.shape[1:])
+            conf = conf.reshape(1, S, *conf.shape[1:])
+            return (preds, conf, side) if self.use_point_feat else (preds, conf)
         if self.pos_embed:
             xr, yr = pos_embed_rows(out.shape[3], size[0], size[1], W, H, out.device)
             out = co.resize(out, size, xr, yr)      # bilinear + position map in one pass
@@ -229,7 +250,6 @@ class DPTHead(nn.Module):
             out = co.resize(out, size)
         if self.for_tracker:
             return out.permute(0, 3, 1, 2)[None]
-        c2 = self.scratch.output_conv2
         out = co.run(self._conv("oc2_0", c2[0]), out, act=1)                 # conv3x3 128->32 + ReLU
         if (c2[2].in_channels == 32 and 2 <= c2[2].out_channels <= 8 and self.activation in _C.HEAD_ACT
                 and self.conf_activation in _C.CONF_ACT):

@@ -105,6 +105,17 @@ int iggt_window_attn_f32(const float* q, long q_ld, int q_mode, const float* k, 
                          long v_ld, float* o, long o_ld, const float* bias, int b, int h, int w, int heads,
                          int head_dim, int ow, int pad, float scale, void* stream);
 
+/* Fused tail of the DPT heads: x [N][Hi][Wi][128] fp32 NHWC -> bilinear upsample (align_corners) to (Ho, Wo) +
+ * separable position map (xpart [Wo][64] on channels 0..63, ypart [Ho][64] on 64..127; both NULL: none) +
+ * conv3x3 128 -> 32 (weights as packed for iggt_conv2d_nhwc_f32: bf16 hi / lo [32][9*128] tap-major, bias b1) + ReLU +
+ * conv1x1 32 -> Cout (w2 [Cout][32], b2) + activate_head: pts [N][Ho][Wo][Cout-1], conf [N][Ho][Wo].
+ * act: 0 linear, 1 exp, 2 relu, 3 inv_log, 4 sigmoid;  conf_act: 0 expp1, 1 expp0, 2 sigmoid.
+ * Replaces custom_interpolate + _apply_pos_embed + scratch.output_conv2 (iggt/heads/dpt_head.py:251-256,274-284,
+ * 121-128,484-509) + activate_head (iggt/heads/head_act.py:61-125) in one pass. */
+int iggt_dpt_tail_f32(const float* x, int N, int Hi, int Wi, int Ho, int Wo, const float* xpart, const float* ypart,
+                      const void* w_hi, const void* w_lo, const float* b1, const float* w2, const float* b2,
+                      float* pts, float* conf, int Cout, int act, int conf_act, void* stream);
+
 /* Mean-input compensation of the 16-bit weight rounding (no counterpart in the reference, which is fp32 on the
  * CPU path this repository is checked against; see iggt_official_amd/precision.py):
  *   iggt_colmean_h16:      mu[k] = mean over rows 0, row_step, 2*row_step, ... of the 16-bit matrix x [rows][K]

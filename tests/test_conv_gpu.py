@@ -160,3 +160,41 @@ def test_conv_transpose_big_tile_path():
     for img in (0, 31):
         ref = F.conv_transpose2d(x[img:img + 1].permute(0, 3, 1, 2).double(), ct.weight.double(), ct.bias.double(), s, 0)
         assert _err(y[img:img + 1].permute(0, 3, 1, 2), ref)[0] < 2e-5
+
+
+@pytest.mark.parametrize("hw_in,size,cout,act,pos", [((37, 45), (64, 78), 4, "inv_log", True),
+                                                     ((19, 19), (37, 37), 2, "exp", True),
+                                                     ((30, 41), (56, 70), 4, "linear", False)])
+def test_dpt_tail_fused_vs_separate_kernels(hw_in, size, cout, act, pos):
+    """Fused upsample + position map + conv3x3 + ReLU + conv1x1 + activate_head kernel against the chain of separately
+    tested kernels (bilinear resize, implicit-GEMM conv, head tail) and against an fp64 PyTorch evaluation."""
+    from iggt_official_amd import _C
+    from iggt_official_amd.heads import convops as co
+
+    N = 3
+    x = _mk((N, hw_in[0], hw_in[1], 128), 41)
+    conv1 = nn.Conv2d(128, 32, 3, 1, 1).cuda()
+    with torch.no_grad():
+        conv1.weight.copy_(_mk(conv1.weight.shape, 42, (128 * 9) ** -0.5))
+        conv1.bias.copy_(_mk((32,), 43, 0.1))
+    w2, b2 = _mk((cout, 32), 44, 0.2), _mk((cout,), 45, 0.2)
+    xr = _mk((size[1], 64), 46, 0.1) if pos else None
+    yr = _mk((size[0], 64), 47, 0.1) if pos else None
+    pc = co.pack_conv2d(conv1)
+    pts, conf = _C.dpt_tail(x, size, xr, yr, pc.w_hi, pc.w_lo, pc.bias, w2, b2, act, "expp1")
+    up = co.resize(x, size, xr, yr)
+    mid = co.run(pc, up, act=1)
+    pts_s, conf_s = _C.head_tail(mid, w2, b2, act, "expp1")
+    assert pts.shape == pts_s.shape and conf.shape == conf_s.shape
+    assert _err(pts, pts_s)[0] < 1e-5 and _err(conf, conf_s)[0] < 1e-5
+    # fp64 reference
+    xd = x.permute(0, 3, 1, 2).double()
+    upd = F.interpolate(xd, size=size, mode="bilinear", align_corners=True)
+    if pos:
+        upd = upd + torch.cat([xr.t()[None, :, None, :].expand(1, 64, size[0], size[1]),
+                               yr.t()[None, :, :, None].expand(1, 64, size[0], size[1])], 1).double()
+    lin = F.conv2d(F.relu(F.conv2d(upd, conv1.weight.double(), conv1.bias.double(), 1, 1)), w2.double()[:, :, None, None],
+                   b2.double()).permute(0, 2, 3, 1)
+    xyz = lin[..., :-1]
+    ref = {"inv_log": torch.sign(xyz) * torch.expm1(xyz.abs()), "exp": xyz.exp(), "linear": xyz}[act]
+    assert _err(pts, ref)[0] < 5e-5 and _err(conf, 1 + lin[..., -1].exp())[0] < 5e-5
