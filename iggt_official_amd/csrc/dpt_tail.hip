@@ -12,8 +12,8 @@
 // 6 x 34 halo of the *upsampled* map directly in LDS -- bilinear sample of the half-resolution map + position row/col
 // value, split into bf16 hi + lo (fp32-grade products, 3 MFMAs per term as in conv_igemm.hip), zero outside the image
 // (the convolution's padding) -- together with that slice's weights for all 9 taps, then runs the 9 taps out of LDS
-// (a tap is a row/column shift of the halo: wave w reads LDS rows (w + ky) * 36 + kx + 0..31) with only two barriers
-// per slice.  Each sample is interpolated and split once instead of nine times, the full-resolution 128- and
+// (a tap is a row/column shift of the halo: wave w reads LDS rows (w + ky) * 36 + kx + 0..31); the weights of a slice
+// are staged in two tap groups so that 48 KB of LDS (three workgroups per CU) suffice.  Each sample is interpolated and split once instead of nine times, the full-resolution 128- and
 // 32-channel maps never exist in HBM, and the epilogue applies bias + ReLU, the 1x1 convolution and the activations
 // and writes 8-16 bytes per pixel.
 #include "common.h"
@@ -25,8 +25,9 @@ constexpr int TH = 4, TW = 32;           // output tile
 constexpr int HH = TH + 2, HWD = TW + 2;   // halo 6 x 34
 constexpr int HP = 36;                   // LDS pitch of a halo row (pixels)
 constexpr int A_PLANE = HH * HP * 64;    // 13 824 B: [halo pixel][32 ch] bf16
-constexpr int W_PLANE = 9 * 32 * 64;     // 18 432 B: [tap * 32 + cout][32 ch] bf16
-constexpr int SMEM_BYTES = 2 * A_PLANE + 2 * W_PLANE;  // 64 512 B
+constexpr int W_TAPS = 5;                // taps staged at a time (5 + 4): 48 KB of LDS -> three workgroups per CU
+constexpr int W_PLANE = W_TAPS * 32 * 64;  // 10 240 B: [(tap - first) * 32 + cout][32 ch] bf16
+constexpr int SMEM_BYTES = 2 * A_PLANE + 2 * W_PLANE;  // 48 128 B
 constexpr int ST_PITCH = 33;             // epilogue tile [128 px][32 ch] fp32, padded
 
 struct TailParams {
@@ -138,41 +139,48 @@ __global__ __launch_bounds__(256, 2) void dpt_tail_kernel(const TailParams p) {
                 }
             }
         }
-        // ---- weights of this slice for all 9 taps: LDS row = tap * 32 + cout, 4 x 16-byte pieces per row ------------
+        // ---- weights + taps in two groups (taps 0-4, then 5-8): LDS row = (tap - first) * 32 + cout --------------------
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+            const int first = grp * W_TAPS, ntap = grp == 0 ? W_TAPS : 9 - W_TAPS;
+            if (grp == 1) __syncthreads();   // taps 0-4 are done with the weight buffer
 #pragma unroll 1
-        for (int pass = 0; pass < 5; ++pass) {
-            const int pi = pass * 256 + tid;
-            if (pi < 9 * 32 * 4) {
-                const int row = pi >> 2, piece = pi & 3;
-                const int co = row & 31, tap = row >> 5;
-                const long src = (long)co * 1152 + tap * 128 + cc * 32 + piece * 8;
-                const int off = swz(row, piece);
-                *reinterpret_cast<u32x4*>(sWh + off) = *reinterpret_cast<const u32x4*>(p.w_hi + src);
-                *reinterpret_cast<u32x4*>(sWl + off) = *reinterpret_cast<const u32x4*>(p.w_lo + src);
+            for (int pass = 0; pass < 3; ++pass) {
+                const int pi = pass * 256 + tid;
+                if (pi < ntap * 32 * 4) {
+                    const int row = pi >> 2, piece = pi & 3;
+                    const int co = row & 31, tap = first + (row >> 5);
+                    const long src = (long)co * 1152 + tap * 128 + cc * 32 + piece * 8;
+                    const int off = swz(row, piece);
+                    *reinterpret_cast<u32x4*>(sWh + off) = *reinterpret_cast<const u32x4*>(p.w_hi + src);
+                    *reinterpret_cast<u32x4*>(sWl + off) = *reinterpret_cast<const u32x4*>(p.w_lo + src);
+                }
             }
-        }
-        __syncthreads();
-        // ---- 9 taps out of LDS: wave = tile row; two accumulators alternate to halve the dependent-MFMA chain -------
+            __syncthreads();
+            // wave = tile row; two accumulators alternate to halve the dependent-MFMA chain
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int arow = (wave + ky) * HP + kx + frow;
-            const int wrow = tap * 32 + frow;
+            for (int tt = 0; tt < W_TAPS; ++tt) {
+                if (tt >= ntap) break;
+                const int tap = first + tt;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int arow = (wave + ky) * HP + kx + frow;
+                const int wrow = tt * 32 + frow;
 #pragma unroll
-            for (int kc = 0; kc < 2; ++kc) {
-                const int aoff = swz(arow, 2 * kc + fhalf), woff = swz(wrow, 2 * kc + fhalf);
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(sAh + aoff);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(sAl + aoff);
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(sWh + woff);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(sWl + woff);
-                if (tap & 1) {
-                    acc1 = mfma32(al, bh, acc1);
-                    acc1 = mfma32(ah, bl, acc1);
-                    acc1 = mfma32(ah, bh, acc1);
-                } else {
-                    acc0 = mfma32(al, bh, acc0);
-                    acc0 = mfma32(ah, bl, acc0);
-                    acc0 = mfma32(ah, bh, acc0);
+                for (int kc = 0; kc < 2; ++kc) {
+                    const int aoff = swz(arow, 2 * kc + fhalf), woff = swz(wrow, 2 * kc + fhalf);
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(sAh + aoff);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(sAl + aoff);
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(sWh + woff);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(sWl + woff);
+                    if (tap & 1) {
+                        acc1 = mfma32(al, bh, acc1);
+                        acc1 = mfma32(ah, bl, acc1);
+                        acc1 = mfma32(ah, bh, acc1);
+                    } else {
+                        acc0 = mfma32(al, bh, acc0);
+                        acc0 = mfma32(ah, bl, acc0);
+                        acc0 = mfma32(ah, bh, acc0);
+                    }
                 }
             }
         }
