@@ -5,8 +5,10 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N ranks, RCCL)
 
 Workload (BASELINE.json configs[2] / [3]): 32 synthetic views @ 518x518, end-to-end forward =
-DINOv2 backbone + 24 x (frame, global) blocks + camera head + depth head + point head, random-init
-weights of the reference architecture (no checkpoint reachable), 16-bit MFMA operands with fp32 accumulation:
+DINOv2 backbone + 24 x (frame, global) blocks + camera head + depth head + point head, seeded synthetic
+weights of the reference architecture (no checkpoint reachable; iggt_official_amd/synthetic.py, the same
+(weights, images) the reference fixture tests/golden/full_s32_518_stress.pt was produced with, so the outputs of the
+TIMED model are compared with the reference's -- `output_check` below), 16-bit MFMA operands with fp32 accumulation:
 fp16 by default -- the format whose outputs stay within 1e-3 of the reference's fp32 CPU path (tests/test_e2e_gpu.py);
 IGGT_OPERAND_DTYPE=bf16 selects the reference's own GPU precision (demo.py:193-195), same MFMA rate.  518 is not a multiple of 28, where
 the reference's part head raises, so the step produces the geometry outputs --
@@ -18,8 +20,12 @@ Prints ONE JSON line (rank 0) with value = total views / second, plus
   "roofline": global-attention flash kernel, algorithmic FLOPs (4*Nq*Nk*C per launch) / mean launch
               duration measured with HIP events on the launch stream inside the timed region, against
               the 2.5 PFLOP/s dense 16-bit (bf16 = fp16) MFMA peak;
+  "output_check": relative l2 / max errors of the timed model's outputs against strided samples of the REFERENCE
+              outputs (fixture produced by the reference modules on CPU fp32 at this very configuration) plus a
+              checksum (mean / abs-sum per output) that tests/test_headline_gpu.py pins through the same fixture;
   "cpu_baseline": the CPU restatement of the reference (oracle/restate.py, kind "port") timed on this
-              box's host cores on a bounded sample (2 views @ 518x518), rank 0 / N=1 only.
+              box's host cores on a bounded sample (4 views @ 518x518 = BASELINE.json configs[0]'s size), plus a
+              32-view figure extrapolated from a row-sampled global attention (flagged as such), rank 0 / N=1 only.
 """
 import argparse
 import json
@@ -36,9 +42,17 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
-# HBM-side bytes per global-attention launch at 32 views x 518^2 on one GPU, from rocprofv3 PMC passes
-# (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE): profiles/r01_attn_hbm_pmc.txt.  Not measurable live.
-PMC_TRAFFIC_BYTES = {(32, 518, 1): 1.17e9}
+# HBM-side bytes per global-attention launch, from rocprofv3 PMC passes on the kernel named in the entry
+# (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes; MI355X_MICROARCH.md section HBM).  PMC counters cannot
+# be read live inside the timed run, so the figure is keyed by (views, size, n_gpus, kernel label) and reported as
+# null whenever the kernel actually launched is not the one it was measured on.
+PMC_TRAFFIC = {}
+try:
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "attn_traffic.json")) as _f:
+        PMC_TRAFFIC = json.load(_f)
+except Exception:  # noqa: BLE001
+    PMC_TRAFFIC = {}
+FIXTURES = {(32, 518): ("full_s32_518_stress", 8), (8, 518): ("full_s8_518_stress", 7)}   # (views, size) -> (fixture, image seed)
 
 
 def usable_cores():
@@ -54,7 +68,11 @@ def usable_cores():
 
 
 def _cpu_baseline_worker(sample_views, size, cores):
-    """(child process) oracle port on the host cores: one `sample_views`-view geometry forward."""
+    """(child process) oracle port on the host cores: one `sample_views`-view geometry forward, then the global
+    attention of ONE view's queries against the keys of `sample_views` and of 32 views (row-sampled: full K/V, 1374
+    query rows) for the extrapolation to the bench configuration."""
+    import torch.nn.functional as F
+
     from oracle import restate, weights
 
     torch.set_num_threads(cores)
@@ -63,8 +81,22 @@ def _cpu_baseline_worker(sample_views, size, cores):
     sd = weights.fill_state_dict(schema, seed=0, mode="default")
     images = weights.make_images(sample_views, size, size, seed=0)
     t0 = time.perf_counter()
-    restate.iggt_forward(sd, images, with_part=False)
-    print(json.dumps({"dt": time.perf_counter() - t0}), flush=True)
+    with torch.no_grad():
+        restate.iggt_forward(sd, images, with_part=False)
+    dt = time.perf_counter() - t0
+    P = 5 + (size // 14) ** 2
+    att = {}
+    with torch.no_grad():
+        for views in (sample_views, 32):
+            g = torch.Generator().manual_seed(views)
+            q = torch.randn(1, 16, P, 64, generator=g)
+            k = torch.randn(1, 16, views * P, 64, generator=g)
+            v = torch.randn(1, 16, views * P, 64, generator=g)
+            F.scaled_dot_product_attention(q[:, :, :64], k, v)   # warm-up
+            t0 = time.perf_counter()
+            F.scaled_dot_product_attention(q, k, v)
+            att[views] = time.perf_counter() - t0
+    print(json.dumps({"dt": dt, "attn_rows": att}), flush=True)
 
 
 def cpu_baseline(sample_views, size, budget_s=240):
@@ -77,14 +109,57 @@ def cpu_baseline(sample_views, size, budget_s=240):
            str(cores)]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s, cwd=ROOT)
-        dt = json.loads(out.stdout.strip().splitlines()[-1])["dt"]
+        rec = json.loads(out.stdout.strip().splitlines()[-1])
+        dt = rec["dt"]
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "views/s", "cores": cores, "kind": "port",
                 "sample": f"{sample_views} view(s) @ {size}x{size} did not finish within {budget_s}s on {cores} cores"}
-    return {"value": sample_views / dt, "unit": "views/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_views} view(s) @ {size}x{size}, full geometry forward (DINOv2 + 24x(frame,global) + "
-                      f"camera/depth/point heads) of oracle/restate.py, fp32 torch CPU, {cores} threads, one run "
-                      f"{dt:.1f}s; global attention is O(S^2), so the per-view CPU rate at 32 views is lower"}
+    res = {"value": sample_views / dt, "unit": "views/s", "cores": cores, "kind": "port",
+           "sample": f"{sample_views} view(s) @ {size}x{size}, full geometry forward (DINOv2 + 24x(frame,global) + "
+                     f"camera/depth/point heads) of oracle/restate.py, fp32 torch CPU, {cores} threads, one run "
+                     f"{dt:.1f}s"}
+    a = {int(k): v for k, v in rec.get("attn_rows", {}).items()}
+    if sample_views in a and 32 in a and sample_views != 32:
+        # per-view time at 32 views = measured per-view time + 24 blocks x (one view's global-attention rows against
+        # 32 views of keys - the same against `sample_views` views of keys); everything else is linear in the views
+        per_view_32 = dt / sample_views + 24.0 * (a[32] - a[sample_views])
+        res["extrapolated_32_views"] = {
+            "value": 1.0 / per_view_32, "unit": "views/s", "extrapolated": True,
+            "how": f"per-view time of the {sample_views}-view run + 24 x (row-sampled global attention: 1374 query rows x "
+                   f"16 heads against 32 views of keys {a[32]:.2f}s - against {sample_views} views {a[sample_views]:.2f}s)"}
+    return res
+
+
+def output_check(pred, S, H, v0, v1, dev):
+    """Compare the timed model's outputs (this rank's views v0:v1) with the reference fixture of this configuration
+    (tests/golden/<fixture>.pt: strided samples written by the REFERENCE modules on CPU fp32, oracle/make_golden.py).
+    Returns None when no fixture exists for (S, H)."""
+    fx = FIXTURES.get((S, H))
+    path = os.path.join(ROOT, "tests", "golden", (fx[0] if fx else "-") + ".pt")
+    if fx is None or not os.path.exists(path):
+        return None
+    g = torch.load(path, map_location="cpu", weights_only=False)
+    ss = g["meta"]["spatial_stride"]
+    out = {"fixture": "tests/golden/" + fx[0] + ".pt", "errors": {}, "checksum": {}}
+    for k in ("depth", "depth_conf", "world_points", "world_points_conf"):
+        got = pred[k][:, :, ::ss, ::ss].double().cpu()
+        ref = g[k][:, v0:v1].double()
+        d = got - ref
+        out["errors"][k] = {"l2": float(d.norm() / ref.norm()), "max": float(d.abs().max() / ref.abs().max())}
+        v = pred[k].double()
+        out["checksum"][k] = {"mean": float(v.mean()), "abs_sum": float(v.abs().sum())}
+        if v0 == 0 and v1 == S:   # whole tensor on this rank: the reference's whole-tensor statistics apply
+            st = g["stats"][k]
+            out["checksum"][k]["ref_mean"] = st["mean"]
+            out["checksum"][k]["ref_abs_sum"] = st["abs_sum"]
+    pe = torch.stack(pred["pose_enc"], 0).double().cpu()
+    ref = g["pose_enc"].double()
+    out["errors"]["pose_enc"] = {"l2": float((pe - ref).norm() / ref.norm()),
+                                 "max": float((pe - ref).abs().max() / ref.abs().max())}
+    out["max_l2"] = max(e["l2"] for e in out["errors"].values())
+    out["tolerance"] = 1e-3
+    out["ok"] = bool(out["max_l2"] < 1e-3)
+    return out
 
 
 def main():
@@ -97,7 +172,9 @@ def main():
     ap.add_argument("--views", type=int, default=32)
     ap.add_argument("--size", type=int, default=518)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-views", type=int, default=1)
+    ap.add_argument("--cpu-sample-views", type=int, default=4)
+    ap.add_argument("--random-init", action="store_true",
+                    help="torch random-init weights and images instead of the synthetic checkpoint (no output check)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,22 +193,36 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from iggt.models.vggt import IGGT
-    from iggt_official_amd import _C, precision, profiling
+    from iggt_official_amd import _C, precision, profiling, synthetic
     from iggt_official_amd.dist import ViewShard, view_partition
 
     _C.load()
     S, H = args.views, args.size
     if S % world:
         raise SystemExit(f"--views {S} must be divisible by the number of GPUs {world}")
-    torch.manual_seed(0)  # identical random-init weights on every rank
+    torch.manual_seed(0)  # identical weights on every rank
     with torch.device(dev):
         model = IGGT(part_on_invalid_grid="skip").eval()
     if world > 1:
         shard = ViewShard()
         model.set_view_shard(shard)
     v0, v1 = view_partition(S, world, rank)
-    g = torch.Generator(device="cpu").manual_seed(1234)
-    images = torch.rand(S, 3, H, H, generator=g)[v0:v1].to(dev)
+    if args.random_init:
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        images = torch.rand(S, 3, H, H, generator=g)[v0:v1].to(dev)
+        data = "synthetic (torch random-init weights, uniform random images)"
+    else:
+        # the synthetic checkpoint + images of the reference fixtures (hash-generated on the device, bit-identical to
+        # the CPU values the reference was run with): the timed outputs can be checked against the reference
+        with open(os.path.join(ROOT, "tests", "golden", "state_dict_schema.json")) as f:
+            schema = json.load(f)
+        sd = synthetic.fill_state_dict(schema, seed=0, mode="stress", device=dev)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        del sd
+        assert not [u for u in unexpected if not u.startswith("track_head.")], unexpected
+        iseed = FIXTURES.get((S, H), (None, 1234))[1]
+        images = synthetic.make_images(S, H, H, seed=iseed, device=dev)[v0:v1].contiguous()
+        data = "synthetic (seeded hash weights 'stress' seed 0 and hash-noise images, iggt_official_amd/synthetic.py)"
 
     def step():
         return model(images)
@@ -156,6 +247,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert all(torch.isfinite(v).all() for v in out.values() if torch.is_tensor(v))
+    check = None if args.random_init else output_check(out, S, H, v0, v1, dev)
+    if world > 1 and check is not None:   # worst rank decides
+        t = torch.tensor([check["max_l2"]], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        check["max_l2_all_ranks"] = float(t.item())
+        check["ok"] = bool(check["max_l2_all_ranks"] < check["tolerance"])
 
     if rank == 0:
         P = 5 + (H // 14) ** 2
@@ -164,6 +261,8 @@ def main():
         ms = sum(r[0] for r in recs) / max(len(recs), 1)
         flops = 4.0 * Nq * Nk * C
         achieved = flops / (ms * 1e-3) / 1e12
+        kernel_label = _C.attn_kernel_label(1, 16, Nq, Nk, precision.operand_name())
+        traffic = PMC_TRAFFIC.get(f"{S}x{H}x{world}:{kernel_label}", {})
         line = {
             "metric": "views/sec (N-view 518^2 forward)",
             "value": S * args.steps / dt,
@@ -176,19 +275,22 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": precision.operand_name(),
-            "data": "synthetic",
+            "data": data,
             "config": {"workload": f"{S} views @ {H}x{H}, IGGT forward (DINOv2 + 24x(frame,global) + camera/depth/"
                                    "point heads), random-init weights, views sharded " + f"{S // world}/GPU",
                        "views": S, "image_size": H, "tokens_per_view": P, "parallelism": f"view-shard x{world}"},
-            "roofline": {"bound": "mfma", "kernel": f"flash_attn_d64_v3_kernel<2,2,{precision.operand_name()}> (global attention)",
+            "roofline": {"bound": "mfma", "kernel": kernel_label + " (global attention)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                         "traffic": PMC_TRAFFIC_BYTES.get((S, H, world)),
-                         "traffic_note": "bytes/launch from rocprofv3 PMC passes, profiles/r01_attn_hbm_pmc.txt",
+                         "traffic": traffic.get("bytes_per_launch"),
+                         "traffic_note": traffic.get("note", "no rocprofv3 PMC pass recorded for this kernel / shape "
+                                                             "(profiles/attn_traffic.json)"),
                          "algorithmic_bytes_per_launch": 4.0 * Nk * C * 2,
                          "launches_timed": len(recs), "ms_per_launch": ms,
                          "flops_per_launch": flops},
         }
+        if check is not None:
+            line["output_check"] = check
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.cpu_sample_views, H)

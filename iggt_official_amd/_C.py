@@ -9,10 +9,12 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libiggt_hip.so")
+# IGGT_HIP_LIB: developer override (A/B builds of the same ABI, probes/); the product always loads the in-tree library
+_LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                           "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -31,14 +33,23 @@ _SIGNATURES = {
     "iggt_flash_attn_f16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                                 _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
                                 _c_float, _c_int, _c_void_p],
+    "iggt_flash_attn_static_bf16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                                        _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
+                                        _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p],
+    "iggt_flash_attn_static_f16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                                       _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
+                                       _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p],
+    "iggt_flash_attn_d64_kernel_name": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_char_p, _c_int],
     "iggt_layernorm_f32": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long,
                            _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p],
     "iggt_qknorm_rope_bf16": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long,
                               _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                              _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_long, _c_long, _c_void_p],
+                              _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_long, _c_long, _c_float, _c_void_p,
+                              _c_void_p],
     "iggt_qknorm_rope_f16": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long,
                              _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                             _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_long, _c_long, _c_void_p],
+                             _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_long, _c_long, _c_float, _c_void_p,
+                             _c_void_p],
     "iggt_im2row_patch14": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p],
     "iggt_colmean_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "iggt_bias_correct_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
@@ -159,6 +170,34 @@ def flash_attn_d64(q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
     return o
 
 
+LOG2E = 1.4426950408889634
+
+
+def flash_attn_d64_static(q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, qkmax, flags,
+                          q_rows_per_wg=0):
+    """Static-bound attention (include/iggt_hip.h): q carries scale * log2(e), qkmax fp32 [32] = per-head norm bounds of
+    q (0..15) and k (16..31) as written by qknorm_rope(..., q_scale, qkmax); flags int32 scratch."""
+    _dev(q, k, v, o, qkmax, flags)
+    sfx = _h16(q, k, v, o)
+    assert qkmax.dtype == torch.float32 and qkmax.numel() >= 32 and qkmax.is_contiguous()
+    assert flags.dtype == torch.int32 and flags.is_contiguous()
+    fn = getattr(load(), f"iggt_flash_attn_static_{sfx}_d64")
+    rc = fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Nq, Nk,
+            q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, qkmax.data_ptr(), flags.data_ptr(), flags.numel(),
+            q_rows_per_wg, _stream())
+    _check(rc, f"iggt_flash_attn_static_{sfx}_d64")
+    return o
+
+
+def attn_kernel_label(B, H, Nq, Nk, operand_name, static_bound=False, q_rows_per_wg=0):
+    """Name of the attention kernel instantiation the dispatcher launches for this shape (for reports)."""
+    buf = ctypes.create_string_buffer(128)
+    rc = load().iggt_flash_attn_d64_kernel_name(B, H, Nq, int(operand_name in ("f16", "fp16")), int(static_bound),
+                                                q_rows_per_wg, buf, 128)
+    _check(rc, "iggt_flash_attn_d64_kernel_name")
+    return buf.value.decode()
+
+
 def layernorm(x0, w, b, out, eps, *, x1=None, rows=None, rows_in=0, rows_stride=0, row_off=0,
               orows_stride=0, orow_off=0, ldx=None, ldo=None):
     """LayerNorm over the last dim of x0 (or of concat(x0, x1)); fp32 in, bf16 / fp16 / fp32 out [rows, C]."""
@@ -178,8 +217,9 @@ def layernorm(x0, w, b, out, eps, *, x1=None, rows=None, rows_in=0, rows_stride=
 
 
 def qknorm_rope(qkv, q_out, k_out, v_out, qw, qb, kw, kb, cos_t, sin_t, T, P, gw, patch_start, eps,
-                heads_per_group=0, k_group_stride=0, v_group_stride=0):
-    _dev(qkv, q_out, k_out, v_out, qw, cos_t)
+                heads_per_group=0, k_group_stride=0, v_group_stride=0, q_scale=1.0, qkmax=None):
+    _dev(qkv, q_out, k_out, v_out, qw, cos_t, qkmax)
+    assert qkmax is None or (qkmax.dtype == torch.float32 and qkmax.numel() >= 32 and qkmax.is_contiguous())
     sfx = _h16(qkv, q_out, k_out) if v_out is None else _h16(qkv, q_out, k_out, v_out)
     assert qkv.shape[-1] == 3072
     fn = getattr(load(), "iggt_qknorm_rope_" + sfx)
@@ -187,7 +227,7 @@ def qknorm_rope(qkv, q_out, k_out, v_out, qw, qb, kw, kb, cos_t, sin_t, T, P, gw
             k_out.data_ptr(), k_out.stride(0), _ptr(v_out), 0 if v_out is None else v_out.stride(0),
             qw.data_ptr(), qb.data_ptr(), kw.data_ptr(), kb.data_ptr(),
             cos_t.data_ptr(), sin_t.data_ptr(), T, P, gw, patch_start, float(eps),
-            heads_per_group, k_group_stride, v_group_stride, _stream())
+            heads_per_group, k_group_stride, v_group_stride, float(q_scale), _ptr(qkmax), _stream())
     _check(rc, "iggt_qknorm_rope_" + sfx)
 
 

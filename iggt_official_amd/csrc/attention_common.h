@@ -13,6 +13,12 @@ struct AttnParams {
     long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;  // in elements
     float scale_log2;  // softmax scale * log2(e)
     int qtiles;
+    // static-bound softmax (attention_v3.hip): qkmax[h] = max_i |q^_i|, qkmax[H + h] = max_j |k^_j| of head h (q^ carries
+    // scale * log2 e), flags[work item] = 1 for query tiles the dynamic kernel has to redo, static_min_l = smallest
+    // acceptable row sum.  flags alone (qkmax == nullptr) gates the dynamic kernel on the flagged tiles.
+    const float* qkmax;
+    int* flags;
+    float static_min_l;
 };
 
 constexpr int KV_TILE = 64;
@@ -40,8 +46,16 @@ IGGT_DEVINL bf16x8 pack8h(const f32x16& s, int base) {
 // in fp16's normal range (smallest normal 6.1e-5 * 2^-8 = 2.4e-7 of the maximum, subnormals to 2.3e-10); the
 // shift cancels in O / l.  bf16 has fp32's exponent range and needs none.
 constexpr float P_SHIFT_F16 = 8.0f;
+// static-bound kernel: numerators 2^(s - c_h + 15) <= 2^15 (fp16 max 2^16); a row is accepted when its row sum is at least
+// 2^15 * 2^-11: the numerators that then fall below fp16's smallest subnormal (2^-24) carry < N * 2^-24 / 2^4 of the row's
+// mass (3e-4 at N = 44k in the worst case of a completely flat row, typically orders of magnitude less).  bf16 numerators
+// have fp32's exponent range: no shift, and the acceptance threshold only guards against fp32 underflow of l.
+constexpr float STATIC_SHIFT_F16 = 15.0f;
+constexpr float STATIC_MIN_L_F16 = 16.0f;
+constexpr float STATIC_MIN_L_BF16 = 1e-30f;
 
 }  // namespace iggt_attn
 
 // experimental variants live in their own translation units
-int iggt_launch_flash_attn_v3(const iggt_attn::AttnParams& p, int q_rows, int kvm, int fmt, hipStream_t stream);
+int iggt_launch_flash_attn_v3(const iggt_attn::AttnParams& p, int q_rows, int kvm, int fmt, bool static_bound,
+                              hipStream_t stream);

@@ -22,6 +22,19 @@
 // the partial round costs ~0.6 of a full one, not 1.0).
 // Ablation: the same kernel without any softmax VALU work reaches 1 210 TF/s -- the d = 64 softmax (64 exp +
 // ~140 other VALU ops per 32 MFMA) is what separates this kernel from the matrix-pipe limit.
+//
+// Round 2: STATIC-BOUND softmax (template parameter STATIC, "v4").  q and k of the aggregator blocks leave the fused
+// q/k-LayerNorm + RoPE kernel with known norms, so by Cauchy-Schwarz  s_ij = q^_i . k^_j <= max|q^| max|k^| =: c_h  holds
+// for every score of head h (q^ already carries softmax scale * log2 e; the two maxima are by-products of that kernel,
+// csrc/elementwise.hip).  The numerators are then  P_ij = 2^(s_ij - c_h + SHIFT)  <= 2^SHIFT  with a shift that is known
+// BEFORE the first tile: no row-max tree, no lane exchange, no wave vote, no rescale of O and l, no branch in the tile
+// loop -- and the subtraction itself is free, because -(c_h - SHIFT) enters as the C operand of the first QK^T MFMA
+// of every score block (one wave-uniform 16-register vector).  Per 32 x 32 score block that leaves 16 v_exp + 16 v_add
+// (row sum) + 8 v_cvt_pk of VALU work beside 8 MFMAs (dynamic kernel: + 16 v_fma + 16 v_max + exchange + vote).
+// What the bound cannot give is a LOWER limit of a row's true maximum: a row whose scores all sit far below c_h ends
+// with numerators in fp16's subnormal range.  Such rows are detected after the loop by their row sum
+// (l_i < 2^SHIFT * STATIC_MIN_L) and their 256-row tile is flagged; the dynamic kernel (same file, gated on the flag
+// array) then recomputes exactly the flagged tiles.  With LayerNorm-ed q, k the slack is ~5 bits of the 29 available.
 #include "attention_common.h"
 #include "../../include/iggt_hip.h"
 
@@ -31,7 +44,13 @@ namespace {
 
 constexpr float DEFER_THR = 4.0f;  // log2 units: P <= 16
 
-template <int QB, int KVM, int FMT>
+#ifdef IGGT_ATTN_NO_PIN   // A/B builds only (probes/build_alt.py)
+constexpr bool PIN_DEFAULT = false;
+#else
+constexpr bool PIN_DEFAULT = true;
+#endif
+
+template <int QB, int KVM, int FMT, bool STATIC, bool PIN = PIN_DEFAULT>
 __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KVM * BUF_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -39,6 +58,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     const int frow = lane & 31, fhalf = lane >> 5;
 
     const int work = xcd_remap(blockIdx.x, gridDim.x);
+    if constexpr (!STATIC) {
+        // fallback pass behind the static-bound kernel: only the flagged query tiles are recomputed
+        if (p.flags != nullptr && p.flags[work] == 0) return;
+    }
     const int qt = work % p.qtiles;
     const int bh = work / p.qtiles;
     const int h = bh % p.H, b = bh / p.H;
@@ -115,6 +138,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     }
     const int tr_i = lane & 15, tr_g = (lane >> 4) & 1;
     const float c = p.scale_log2;
+    // static bound: the (negated) shift enters through the accumulator input of the first QK^T MFMA of a score block
+    f32x16 cinit;
+    if constexpr (STATIC) {
+        const float shift = p.qkmax[h] * p.qkmax[p.H + h] * 1.00002f + 1e-3f - (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cinit[r] = -shift;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+    }
     const int NT = (p.Nk + KV_TILE - 1) / KV_TILE;
 
     // ---- building blocks ---------------------------------------------------------------------
@@ -135,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kvh * 4096 + koff[kc]);
-                s[kvh] = mfma32h<FMT>(kf, qf[qb][kc], kc == 0 ? zero : s[kvh]);
+                s[kvh] = mfma32h<FMT>(kf, qf[qb][kc], kc == 0 ? (STATIC ? cinit : zero) : s[kvh]);
             }
         }
     };
@@ -179,8 +212,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         for (int kvh = 0; kvh < 2; ++kvh) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float a = __builtin_fmaf(s[kvh][r], c, -m);
-                s[kvh][r] = __builtin_amdgcn_exp2f(a);
+                if constexpr (STATIC) {
+                    s[kvh][r] = __builtin_amdgcn_exp2f(s[kvh][r]);   // the accumulator already holds s - c_h + SHIFT
+                } else {
+                    const float a = __builtin_fmaf(s[kvh][r], c, -m);
+                    s[kvh][r] = __builtin_amdgcn_exp2f(a);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {
@@ -212,6 +249,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                 }
     };
 
+    // keep the packed numerators of q-block 0 "used" right behind exp/pack: without this hipcc sinks the whole exp/pack(q0)
+    // group below the run-time tail branch that follows QK^T(q1), i.e. out of the basic block in which it is meant to
+    // run beside those MFMAs (round-1 code: QK^T(q1) ran bare and PV(q0), PV(q1) shared one block with ALL the VALU work)
+    auto pin = [&](bf16x8 (&pf)[2][2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u32x4 w = __builtin_bit_cast(u32x4, pf[i][j]);
+                asm volatile("" : "+v"(w));
+                pf[i][j] = __builtin_bit_cast(bf16x8, w);
+            }
+    };
     const int NMT = (NT + KVM - 1) / KVM;
     dma(0, 0);
     __syncthreads();  // vmcnt(0) + barrier: macro tile 0 resident
@@ -228,12 +278,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                 bf16x8 pf0[2][2], pf1[2][2];
                 qk(sK, 0, s0);
                 if (tail) mask_tail(t, s0);
-                update_max(0, s0);
+                if constexpr (!STATIC) update_max(0, s0);
                 if constexpr (QB == 2) {
                     qk(sK, 1, s1);
                     exp_pack(0, s0, pf0);
+                    if constexpr (PIN) pin(pf0);
                     if (tail) mask_tail(t, s1);
-                    update_max(1, s1);
+                    if constexpr (!STATIC) update_max(1, s1);
                     pv(sV, 0, pf0);
                     exp_pack(1, s1, pf1);
                     pv(sV, 1, pf1);
@@ -246,11 +297,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         __syncthreads();  // everyone done with buffer mt&1; DMA of macro tile mt+1 landed
     }
 
+    bool weak = false;   // static bound only: some row's numerators sank towards the subnormal range
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int qr = q_base + qb * 32 + frow;
         const float l = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
         const float inv = 1.0f / l;
+        if constexpr (STATIC) weak = weak || (qr < p.Nq && !(l >= p.static_min_l));
         if (qr < p.Nq) {
             bf16_t* dst = ob_ptr + (long)qr * p.o_rs + 4 * fhalf;
 #pragma unroll
@@ -264,29 +317,37 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                 }
         }
     }
+    if constexpr (STATIC) {
+        if (weak) p.flags[work] = 1;   // benign race: every writer stores 1; the gated dynamic pass recomputes the tile
+    }
 }
 
 }  // namespace
 
-// Launched from iggt_flash_attn_bf16_d64 (attention.hip): code = 256 | 128 (q rows per WG) + 1000 * KVM.
-template <int FMT>
+// Launched from the dispatcher in attention.hip: q_rows = 256 | 128 query rows per workgroup, kvm = 64-key tiles per macro tile.
+template <int FMT, bool STATIC>
 static void launch_v3(const AttnParams& p_in, int q_rows, int kvm, hipStream_t stream) {
     AttnParams p = p_in;
     if (q_rows == 256) {
         p.qtiles = (p.Nq + 255) / 256;
         const dim3 grid(p.B * p.H * p.qtiles), block(256);
-        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2, FMT>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 1, FMT>), grid, block, 0, stream, p);
+        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2, FMT, STATIC>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 1, FMT, STATIC>), grid, block, 0, stream, p);
     } else {
         p.qtiles = (p.Nq + 127) / 128;
         const dim3 grid(p.B * p.H * p.qtiles), block(256);
-        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 2, FMT>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 1, FMT>), grid, block, 0, stream, p);
+        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 2, FMT, STATIC>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 1, FMT, STATIC>), grid, block, 0, stream, p);
     }
 }
 
-int iggt_launch_flash_attn_v3(const AttnParams& p, int q_rows, int kvm, int fmt, hipStream_t stream) {
-    if (fmt == FMT_F16) launch_v3<FMT_F16>(p, q_rows, kvm, stream);
-    else launch_v3<FMT_BF16>(p, q_rows, kvm, stream);
+int iggt_launch_flash_attn_v3(const AttnParams& p, int q_rows, int kvm, int fmt, bool static_bound, hipStream_t stream) {
+    if (static_bound) {
+        if (fmt == FMT_F16) launch_v3<FMT_F16, true>(p, q_rows, kvm, stream);
+        else launch_v3<FMT_BF16, true>(p, q_rows, kvm, stream);
+    } else {
+        if (fmt == FMT_F16) launch_v3<FMT_F16, false>(p, q_rows, kvm, stream);
+        else launch_v3<FMT_BF16, false>(p, q_rows, kvm, stream);
+    }
     return 0;
 }

@@ -147,6 +147,11 @@ struct QkParams {
     // goes to  out + (h / hg) * group_stride + t * ld + (h % hg) * 64.   hg = 16, stride 0: flat [T][C] rows.
     int hg;
     long kgs, vgs;
+    // static-bound softmax (attention_v3.hip): q is written pre-multiplied by q_scale (softmax scale * log2 e; 1 = off) and
+    // the largest Euclidean norms of the ROUNDED q and k head vectors are accumulated into qkmax[h] / qkmax[16 + h]
+    // (atomic max on the bit pattern of a non-negative float; nullptr = off).  The buffer is zeroed by the entry point.
+    float q_scale;
+    float* qkmax;
 };
 
 template <int FMT>
@@ -195,9 +200,28 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
         const float cs = p.cos_t[pos * 16 + f0 + e], sn = p.sin_t[pos * 16 + f0 + e];
         y[e] = x[e] * cs + rot * sn;
     }
+    if (which == 0 && p.q_scale != 1.0f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] *= p.q_scale;
+    }
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = pack_h2<FMT>(y[2 * e], y[2 * e + 1]);
+    if (p.qkmax != nullptr) {   // |rounded vector|: 8 lanes of a head reduce; most tokens lose against the running maximum
+        float n2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = h2_lo<FMT>(o[e]), b2 = h2_hi<FMT>(o[e]);
+            n2 += a * a + b2 * b2;
+        }
+        n2 += __shfl_xor(n2, 1, 64); n2 += __shfl_xor(n2, 2, 64); n2 += __shfl_xor(n2, 4, 64);
+        if (j == 0) {
+            const float nrm = sqrtf(n2);
+            unsigned int* slot = reinterpret_cast<unsigned int*>(p.qkmax) + which * 16 + head;
+            const unsigned int bits = __builtin_bit_cast(unsigned int, nrm);
+            if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+        }
+    }
     const int hgrp = head / p.hg, hin = head - hgrp * p.hg;
     bf16_t* dst = which ? (p.k_out + hgrp * p.kgs + (long)t * p.ldk + hin * 64) : (p.q_out + (long)t * p.ldq + head * 64);
     *reinterpret_cast<u32x4*>(dst + j * 8) = o;
@@ -540,8 +564,10 @@ extern "C" int iggt_layernorm_f32(const float* x0, long ld0, const float* x1, lo
 static int qknorm_rope_h16(int fmt, const void* qkv, long ld_in, void* q_out, long ldq, void* k_out, long ldk,
                            void* v_out, long ldv, const float* qw, const float* qb, const float* kw, const float* kb,
                            const float* cos_t, const float* sin_t, int T, int P, int gw, int patch_start, float eps,
-                           int heads_per_group, long k_group_stride, long v_group_stride, void* stream) {
+                           int heads_per_group, long k_group_stride, long v_group_stride, float q_scale, float* qkmax,
+                           void* stream) {
     if (T <= 0 || P <= 0) return -1;
+    if (!(q_scale > 0.f)) return -4;
     if ((ld_in % 8) || (ldq % 8) || (ldk % 8) || (v_out && (ldv % 8))) return -2;
     QkParams p;
     p.qkv = (const bf16_t*)qkv; p.ld_in = ld_in;
@@ -555,6 +581,11 @@ static int qknorm_rope_h16(int fmt, const void* qkv, long ld_in, void* q_out, lo
         if ((16 % heads_per_group) || (k_group_stride % 8) || (v_group_stride % 8)) return -3;
         p.hg = heads_per_group; p.kgs = k_group_stride; p.vgs = v_group_stride;
     }
+    p.q_scale = q_scale; p.qkmax = qkmax;
+    if (qkmax != nullptr) {
+        const hipError_t e = hipMemsetAsync(qkmax, 0, 32 * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
     if (fmt == FMT_F16) hipLaunchKernelGGL(qknorm_rope_kernel<FMT_F16>, dim3(T), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(qknorm_rope_kernel<FMT_BF16>, dim3(T), dim3(256), 0, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
@@ -565,18 +596,18 @@ extern "C" int iggt_qknorm_rope_bf16(const void* qkv, long ld_in, void* q_out, l
                                      void* v_out, long ldv, const float* qw, const float* qb, const float* kw,
                                      const float* kb, const float* cos_t, const float* sin_t, int T, int P,
                                      int gw, int patch_start, float eps, int heads_per_group, long k_group_stride,
-                                     long v_group_stride, void* stream) {
+                                     long v_group_stride, float q_scale, float* qkmax, void* stream) {
     return qknorm_rope_h16(FMT_BF16, qkv, ld_in, q_out, ldq, k_out, ldk, v_out, ldv, qw, qb, kw, kb, cos_t, sin_t, T, P,
-                           gw, patch_start, eps, heads_per_group, k_group_stride, v_group_stride, stream);
+                           gw, patch_start, eps, heads_per_group, k_group_stride, v_group_stride, q_scale, qkmax, stream);
 }
 
 extern "C" int iggt_qknorm_rope_f16(const void* qkv, long ld_in, void* q_out, long ldq, void* k_out, long ldk,
                                     void* v_out, long ldv, const float* qw, const float* qb, const float* kw,
                                     const float* kb, const float* cos_t, const float* sin_t, int T, int P,
                                     int gw, int patch_start, float eps, int heads_per_group, long k_group_stride,
-                                    long v_group_stride, void* stream) {
+                                    long v_group_stride, float q_scale, float* qkmax, void* stream) {
     return qknorm_rope_h16(FMT_F16, qkv, ld_in, q_out, ldq, k_out, ldk, v_out, ldv, qw, qb, kw, kb, cos_t, sin_t, T, P,
-                           gw, patch_start, eps, heads_per_group, k_group_stride, v_group_stride, stream);
+                           gw, patch_start, eps, heads_per_group, k_group_stride, v_group_stride, q_scale, qkmax, stream);
 }
 
 extern "C" int iggt_im2row_patch14(const float* img, void* out, int out_f16, int S, int H, int W, int Kpad,

@@ -73,14 +73,17 @@ class ViewShard:
         self._gather(out, kv_local)
         return out
 
+    def _flat(self) -> bool:
+        """RCCL ("nccl"): one flat all_gather_into_tensor.  gloo (host-logic tests, the single-GPU two-rank test) lacks the
+        flat variant for some tensors, so it always takes the list form.  The variant is a property of the BACKEND, chosen
+        once: a failing collective must surface as an error, never be re-issued as a different collective on one rank."""
+        return dist.get_backend(self.group) == "nccl"
+
     def _gather(self, out, x):
-        """all_gather_into_tensor (RCCL: one direct all-gather); list-based fallback for backends that lack the
-        flat variant for device tensors (gloo, used by the single-GPU two-rank test)."""
-        try:
+        if self._flat():
             dist.all_gather_into_tensor(out, x, group=self.group)
-        except (RuntimeError, NotImplementedError):
-            parts = list(out.view(self.world, *x.shape).unbind(0))
-            dist.all_gather(parts, x, group=self.group)
+        else:
+            dist.all_gather(list(out.view(self.world, *x.shape).unbind(0)), x, group=self.group)
 
     def gather_kv_groups(self, kv_local: torch.Tensor):
         """kv_local [G, T_l, D] (contiguous, head-group layout) -> list of G (work, kv_all_g [world*T_l, D]).
@@ -91,9 +94,9 @@ class ViewShard:
         out = self._buf("kv_groups", (G, self.world * Tl, D), kv_local)
         handles = []
         for g in range(G):
-            try:
+            if self._flat():
                 work = dist.all_gather_into_tensor(out[g], kv_local[g], group=self.group, async_op=True)
-            except (RuntimeError, NotImplementedError):   # backends without the flat variant (gloo)
+            else:
                 work = dist.all_gather(list(out[g].view(self.world, Tl, D).unbind(0)), kv_local[g], group=self.group,
                                        async_op=True)
             handles.append((work, out[g]))

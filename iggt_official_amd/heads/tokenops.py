@@ -52,7 +52,7 @@ def linear(lin: nn.Linear, x: torch.Tensor, act: int = 0, res: torch.Tensor = No
     r2 = None
     if res is not None:
         r2 = res.reshape(1, 1, -1, Cout)
-        if not r2.is_contiguous():
-            r2 = r2.contiguous()
+        if not r2.is_contiguous() or r2.dtype != torch.float32:
+            r2 = r2.float().contiguous()
     y = co.run(pc, x2, act=act, res=r2)
     return y.view(*x.shape[:-1], Cout)

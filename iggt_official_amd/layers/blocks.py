@@ -170,6 +170,11 @@ class Block(nn.Module):
             if self.attn.qk_norm:
                 self._packed.update(qw=f32(self.attn.q_norm.weight), qb=f32(self.attn.q_norm.bias),
                                     kw=f32(self.attn.k_norm.weight), kb=f32(self.attn.k_norm.bias))
+                # data-independent bound of |k| for the static-bound softmax when K comes from other ranks:
+                # |LayerNorm(x) * w + b| <= sqrt(d) * max|w| + |b|; RoPE is a rotation; 2^-8 covers the 16-bit rounding
+                kw_, kb_ = self._packed["kw"], self._packed["kb"]
+                bound = (kw_.abs().max() * (self.attn.head_dim ** 0.5) + kb_.norm()) * (1.0 + 2.0 ** -8)
+                self._packed["k_bound"] = bound.reshape(1).expand(16).contiguous()
             self._packed_key = key
         return self._packed
 
@@ -203,12 +208,18 @@ class Block(nn.Module):
         _C.gemm_h16(xn, pk["w_qkv"], qkv, bias=compensated_bias(ws, xn, pk["dw_qkv"], pk["b_qkv"]))
         k_src, v_src, kv_rs, Nk, k_bs = qkv[:, C:], qkv[:, 2 * C:], 3 * C, tokens, tokens * 3 * C
         grouped = None
+        # static-bound softmax (csrc/attention_v3.hip): q leaves the q/k-norm kernel pre-scaled by scale * log2 e together
+        # with the per-head maxima of |q| and |k|; not for the head-group pipelined gather (per-group launches)
+        static = (self.attn.qk_norm and precision.static_softmax() and H == 16
+                  and getattr(kv_gather, "kv_groups", 1) <= 1)
+        qkmax = ws.get("qkmax", (32,), torch.float32, dev) if static else None
+        sk = dict(q_scale=self.attn.scale * _C.LOG2E, qkmax=qkmax) if static else {}
         if self.attn.qk_norm:
             assert rope_geom is not None
             qk_args = (pk["qw"], pk["qb"], pk["kw"], pk["kb"], rope_geom["cos"], rope_geom["sin"], T, rope_geom["P"],
                        rope_geom["gw"], rope_geom["patch_start"], self.attn.q_norm.eps)
             if kv_gather is None:
-                _C.qknorm_rope(qkv, qkv, qkv[:, C:], None, *qk_args)
+                _C.qknorm_rope(qkv, qkv, qkv[:, C:], None, *qk_args, **sk)
             elif getattr(kv_gather, "kv_groups", 1) > 1:
                 # multi-GPU, pipelined over head groups (dist.py): K|V of head group g in kv_local[g]
                 assert batch == 1
@@ -222,7 +233,9 @@ class Block(nn.Module):
             else:
                 gather = kv_gather.all_gather_kv if hasattr(kv_gather, "all_gather_kv") else kv_gather
                 kv_local = ws.get("kv_local", (T, 2 * C), dt, dev)
-                _C.qknorm_rope(qkv, qkv, kv_local, kv_local[:, C:], *qk_args)
+                _C.qknorm_rope(qkv, qkv, kv_local, kv_local[:, C:], *qk_args, **sk)
+                if static:   # keys of the other ranks: the data-independent bound instead of this rank's maximum
+                    qkmax[16:].copy_(pk["k_bound"])
                 kv_all = gather(kv_local)
                 assert batch == 1
                 k_src, v_src, kv_rs, Nk, k_bs = kv_all, kv_all[:, C:], 2 * C, kv_all.shape[0], 0
@@ -230,9 +243,15 @@ class Block(nn.Module):
             raise _C.HipExtensionError("kv_gather needs a q/k-norm block")
         if grouped is None:
             with profiling.region("global_attn" if batch == 1 else "frame_attn", (batch, tokens, Nk)):
-                _C.flash_attn_d64(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
-                                  tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,
-                                  self.attn.scale, q_rows_per_wg)
+                if static:
+                    flags = ws.get("attn_flags", (batch * H * ((tokens + 127) // 128),), torch.int32, dev)
+                    _C.flash_attn_d64_static(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
+                                             tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,
+                                             qkmax, flags, q_rows_per_wg)
+                else:
+                    _C.flash_attn_d64(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
+                                      tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,
+                                      self.attn.scale, q_rows_per_wg)
         else:
             G, hg, D, handles = grouped
             main = torch.cuda.current_stream()

@@ -2,9 +2,11 @@
 iggt/models/vggt.py:14-230; caller: demo.py:35,102-121,195).
 
 Same constructor, sub-module attribute names, state-dict keys (track_head excepted, see below) and
-output dict (keys, shapes, fp32) as the reference; the forward runs on MI355X HIP kernels (aggregator,
-head token stages) and PyTorch-ROCm ops (conv pyramids, round 1).  There is no CPU path: inputs and
-parameters must live on the GPU and libiggt_hip.so must be built, otherwise forward raises.
+output dict (keys, shapes, fp32) as the reference; the forward runs on MI355X HIP kernels (aggregator, DPT / part /
+adaptor / camera heads: csrc/*.hip behind include/iggt_hip.h).  There is no CPU path: inputs and parameters must live on
+the GPU and libiggt_hip.so must be built, otherwise forward raises.  Like the reference (vggt.py:66,189) the forward runs
+with autocast DISABLED whatever the caller's context (demo.py:193-195 calls the model under autocast(bf16)): the 16-bit
+operand format of the trunk is the kernels' own (iggt_official_amd/precision.py), outputs are always fp32.
 
 Deliberate differences, all documented in DESIGN.md:
   * S > 12 views works (the reference's chunked head path is broken there, appendix D.1): heads
@@ -48,11 +50,25 @@ class _Base(nn.Module, PyTorchModelHubMixin):
                                       "(reference vggt.py:220-227; demo.py never passes query_points)")
         if images.dim() == 4:
             images = images.unsqueeze(0)
+        if images.dim() != 5:
+            raise ValueError(f"images must be [S,3,H,W] or [B,S,3,H,W], got {tuple(images.shape)}")
         if not images.is_cuda:
             raise _C.HipExtensionError("IGGT forward runs on the MI355X only: move model and images to 'cuda' "
                                        "(no CPU fallback; the CPU restatement lives in oracle/ for tests)")
         _C.load()
         return images.float().contiguous()
+
+    def _scenes(self, images, query_points):
+        """B > 1 (reference vggt.py:149: images [B,S,3,H,W]): scenes are independent, so they run one after the other
+        through the single-scene path and the outputs are concatenated along the batch dimension."""
+        outs = [self.forward(images[b], query_points) for b in range(images.shape[0])]
+        pred = {}
+        for k, v in outs[0].items():
+            if k == "pose_enc":
+                pred[k] = [torch.cat([o[k][i] for o in outs], 0) for i in range(len(v))]
+            else:
+                pred[k] = torch.cat([o[k] for o in outs], 0)
+        return pred
 
     def _camera(self, tokens_list):
         shard = self.aggregator.shard
@@ -76,12 +92,16 @@ class VGGT(_Base):
 
     @torch.no_grad()
     def forward(self, images, query_points=None):
-        images = self._common(images, query_points)
-        tokens, psi = self.aggregator(images)
-        pred = {"pose_enc": self._camera(tokens)}
-        pred["depth"], pred["depth_conf"] = self.depth_head(tokens, images=images, patch_start_idx=psi)
-        pred["world_points"], pred["world_points_conf"] = self.point_head(tokens, images=images, patch_start_idx=psi)
-        pred["images"] = images
+        with torch.amp.autocast("cuda", enabled=False):   # reference vggt.py:66
+            images = self._common(images, query_points)
+            if images.shape[0] != 1:
+                return self._scenes(images, query_points)
+            tokens, psi = self.aggregator(images)
+            pred = {"pose_enc": self._camera(tokens)}
+            pred["depth"], pred["depth_conf"] = self.depth_head(tokens, images=images, patch_start_idx=psi)
+            pred["world_points"], pred["world_points_conf"] = self.point_head(tokens, images=images,
+                                                                              patch_start_idx=psi)
+            pred["images"] = images
         return pred
 
 
@@ -106,20 +126,23 @@ class IGGT(_Base):
         """images [S,3,H,W] or [1,S,3,H,W] in [0,1] (this rank's views when sharded) -> dict with
         pose_enc (list of 4 x [1,S_all,9]), depth [1,S,H,W,1], depth_conf [1,S,H,W],
         world_points [1,S,H,W,3], world_points_conf [1,S,H,W], part_feat [1,S,8,H,W], images."""
-        images = self._common(images, query_points)
-        H, W = images.shape[-2:]
-        part_ok = (H % 28 == 0) and (W % 28 == 0)
-        if not part_ok and self.part_on_invalid_grid == "raise":
-            raise ValueError(f"IGGT part head needs H, W multiples of 28, got {H}x{W} (the reference fails in "
-                             "window_sa.py:73); construct IGGT(part_on_invalid_grid='skip') for geometry only")
-        tokens, psi = self.aggregator(images)
-        pred = {"pose_enc": self._camera(tokens)}
-        pred["depth"], pred["depth_conf"] = self.depth_head(tokens, images=images, patch_start_idx=psi)
-        pts, conf, point_feat = self.point_head(tokens, images=images, patch_start_idx=psi)
-        pred["world_points"], pred["world_points_conf"] = pts, conf
-        if part_ok:
-            pyramid, _ = self.part_adaptor(tokens, images=images, patch_start_idx=psi)
-            pred["part_feat"] = self.part_head(list(pyramid.values()), point_feature=point_feat, images=images,
-                                               patch_start_idx=psi)
-        pred["images"] = images
+        with torch.amp.autocast("cuda", enabled=False):   # reference vggt.py:189: the caller's autocast never reaches the kernels
+            images = self._common(images, query_points)
+            if images.shape[0] != 1:
+                return self._scenes(images, query_points)
+            H, W = images.shape[-2:]
+            part_ok = (H % 28 == 0) and (W % 28 == 0)
+            if not part_ok and self.part_on_invalid_grid == "raise":
+                raise ValueError(f"IGGT part head needs H, W multiples of 28, got {H}x{W} (the reference fails in "
+                                 "window_sa.py:73); construct IGGT(part_on_invalid_grid='skip') for geometry only")
+            tokens, psi = self.aggregator(images)
+            pred = {"pose_enc": self._camera(tokens)}
+            pred["depth"], pred["depth_conf"] = self.depth_head(tokens, images=images, patch_start_idx=psi)
+            pts, conf, point_feat = self.point_head(tokens, images=images, patch_start_idx=psi)
+            pred["world_points"], pred["world_points_conf"] = pts, conf
+            if part_ok:
+                pyramid, _ = self.part_adaptor(tokens, images=images, patch_start_idx=psi)
+                pred["part_feat"] = self.part_head(list(pyramid.values()), point_feature=point_feat, images=images,
+                                                   patch_start_idx=psi)
+            pred["images"] = images
         return pred

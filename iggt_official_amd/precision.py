@@ -59,3 +59,18 @@ def set_mean_compensation(on: bool) -> None:
 
 def operand_name() -> str:
     return "f16" if _operand == torch.float16 else "bf16"
+
+
+# Static-bound softmax of the aggregator blocks (csrc/attention_v3.hip): numerators 2^(s - |q|max |k|max) with a shift known
+# before the first key tile; rows that would underflow are recomputed by the online-max kernel.  IGGT_STATIC_SOFTMAX=0
+# selects the online-max kernel for every attention.
+_static_softmax = os.environ.get("IGGT_STATIC_SOFTMAX", "1") != "0"
+
+
+def static_softmax() -> bool:
+    return _static_softmax
+
+
+def set_static_softmax(on: bool) -> None:
+    global _static_softmax
+    _static_softmax = bool(on)

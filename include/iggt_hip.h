@@ -45,9 +45,8 @@ int iggt_gemm_f16(const void* A, long lda, const void* W, long ldw, int M, int N
                   int rows_in, int rows_out, int row_off, void* stream);
 
 /* softmax(scale * Q K^T) V, head dim 64, bf16 in/out, fp32 softmax; element (b,h,n,d) at
- * ptr + b*bs + n*rs + h*64 + d.  q_rows_per_wg: 0 (auto: the production kernel, tile chosen by shape); explicit
- * codes 5128 / 5256 / 6128 / 6256 (production kernel, 128 / 256 query rows per workgroup, 64 / 128-key macro
- * tiles) and, bf16 only, 128 / 256 / 512 (earlier kernel generations kept for A/B tests).
+ * ptr + b*bs + n*rs + h*64 + d.  q_rows_per_wg: 0 (auto: tile chosen by shape) or an explicit code
+ * 5128 / 5256 / 6128 / 6256 (128 / 256 query rows per workgroup, 64 / 128-key macro tiles).
  * Replaces F.scaled_dot_product_attention (iggt/layers/attention.py:60-66). */
 int iggt_flash_attn_bf16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
                              int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
@@ -57,6 +56,27 @@ int iggt_flash_attn_f16_d64(const void* q, const void* k, const void* v, void* o
                             int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
                             long v_bs, long v_rs, long o_bs, long o_rs, float scale,
                             int q_rows_per_wg, void* stream);
+
+/* The same attention with a STATIC softmax bound (csrc/attention_v3.hip): q must already carry scale * log2(e)
+ * (iggt_qknorm_rope_* with q_scale) and qkmax[h] >= max_i |q_i|, qkmax[16 + h] >= max_j |k_j| (Euclidean norms of the
+ * 16-bit head vectors; by Cauchy-Schwarz every score of head h is <= qkmax[h] * qkmax[16 + h]), so the numerators are
+ * 2^(s - bound) from the first tile on: no running maximum, no rescale.  Rows whose numerators would sink into the
+ * 16-bit subnormal range (row sum below a fixed threshold) get their query tile flagged in `flags` (int[flags_len],
+ * scratch, >= B * H * ceil(Nq / 128) entries, zeroed here) and are recomputed by the online-max kernel in the same call, so
+ * the result meets the tolerance of iggt_flash_attn_* for ANY input.  Same reference operation as above. */
+int iggt_flash_attn_static_bf16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
+                                    int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
+                                    long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
+                                    int* flags, int flags_len, int q_rows_per_wg, void* stream);
+int iggt_flash_attn_static_f16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
+                                   int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
+                                   long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
+                                   int* flags, int flags_len, int q_rows_per_wg, void* stream);
+
+/* Writes the name of the kernel instantiation the attention dispatcher picks for a shape into buf (host only, no launch;
+ * buf_len >= 64): reports must name the kernel that actually ran. */
+int iggt_flash_attn_d64_kernel_name(int B, int H, int Nq, int f16, int static_bound, int q_rows_per_wg,
+                                    char* buf, int buf_len);
 
 /* LayerNorm over C in {128 (no concat / remap), 256, 512, 1024, 2048}; fp32 in ((x0|x1) concatenation when x1 != NULL); out_type 0 = bf16,
  * 1 = fp32, 2 = fp16; optional input-row remap in_row = (r / rows_in) * rows_stride + row_off + r % rows_in and
@@ -71,18 +91,20 @@ int iggt_layernorm_f32(const float* x0, long ld0, const float* x1, long ld1, con
 /* Per-head LayerNorm(64) on q,k + 2-D RoPE (+ optional v copy) on a 16-bit [T][3*1024] qkv matrix.
  * cos_t/sin_t: fp32 [max_pos+1][16].  heads_per_group in {1,2,4,8} writes k / v in head-group layout -- head h of
  * token t at out + (h / hpg) * group_stride + t * ld + (h % hpg) * 64 -- so that the multi-GPU K/V all-gather can be
- * pipelined over head groups (iggt_official_amd/dist.py); 0 or 16: flat rows.  Replaces iggt/layers/attention.py:54-58 and
+ * pipelined over head groups (iggt_official_amd/dist.py); 0 or 16: flat rows.  q_scale (> 0; 1 = none) is folded into the q
+ * output (the softmax scale * log2 e for iggt_flash_attn_static_*); qkmax (float[32] or NULL): receives the largest norm of
+ * the written q (entries 0..15, per head) and k (16..31) head vectors.  Replaces iggt/layers/attention.py:54-58 and
  * iggt/layers/rope.py:119-188 (positions: iggt/models/aggregator.py:236-245). */
 int iggt_qknorm_rope_bf16(const void* qkv, long ld_in, void* q_out, long ldq, void* k_out, long ldk,
                           void* v_out, long ldv, const float* qw, const float* qb, const float* kw,
                           const float* kb, const float* cos_t, const float* sin_t, int T, int P,
                           int gw, int patch_start, float eps, int heads_per_group, long k_group_stride,
-                          long v_group_stride, void* stream);
+                          long v_group_stride, float q_scale, float* qkmax, void* stream);
 int iggt_qknorm_rope_f16(const void* qkv, long ld_in, void* q_out, long ldq, void* k_out, long ldk,
                          void* v_out, long ldv, const float* qw, const float* qb, const float* kw,
                          const float* kb, const float* cos_t, const float* sin_t, int T, int P,
                          int gw, int patch_start, float eps, int heads_per_group, long k_group_stride,
-                         long v_group_stride, void* stream);
+                         long v_group_stride, float q_scale, float* qkmax, void* stream);
 
 /* ImageNet-normalise + im2row of 14x14 patches: img fp32 [S][3][H][W] -> bf16 (out_f16 = 0) or fp16 (1)
  * [S*gh*gw][Kpad].  Replaces iggt/models/aggregator.py:206 and the unfold half of iggt/layers/patch_embed.py:75. */

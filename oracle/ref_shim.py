@@ -31,17 +31,34 @@ def _mod(name):
     return m
 
 
+def _is_reference(mod) -> bool:
+    """True when `mod` (the `iggt` package object) resolves inside REF_ROOT and nowhere else."""
+    paths = [os.path.realpath(p) for p in list(getattr(mod, "__path__", []) or [])]
+    root = os.path.realpath(os.path.join(REF_ROOT, "iggt"))
+    return bool(paths) and all(p == root for p in paths)
+
+
 def install():
-    """Make `import iggt...` resolve to the reference tree. Idempotent."""
+    """Make `import iggt...` resolve to the REFERENCE tree and to nothing else.  Idempotent.
+
+    The repository ships its own regular package `iggt/` (the drop-in alias of the product), which wins over the
+    reference's namespace package whatever the order of sys.path.  So the top-level `iggt` module is built here by
+    hand with `submodule_search_locations = [REF_ROOT/iggt]`: every `iggt.*` import below it can only be served from
+    the reference checkout.  `assert_reference()` re-checks that after the model classes are imported."""
+    import importlib.machinery
+
     import torch
 
-    if "iggt" in sys.modules and getattr(sys.modules["iggt"], "__file__", "").startswith(REF_ROOT):
+    if "iggt" in sys.modules and _is_reference(sys.modules["iggt"]):
         return
-    # a product-side `iggt` alias package may already be imported: drop it
+    # a product-side `iggt` alias package may already be imported: drop it (and every sub-module)
     for k in [k for k in sys.modules if k == "iggt" or k.startswith("iggt.")]:
         del sys.modules[k]
+    spec = importlib.machinery.ModuleSpec("iggt", None, is_package=True)
+    spec.submodule_search_locations = [os.path.join(REF_ROOT, "iggt")]
+    sys.modules["iggt"] = importlib.util.module_from_spec(spec)
     if REF_ROOT not in sys.path:
-        sys.path.insert(0, REF_ROOT)
+        sys.path.append(REF_ROOT)   # for the reference's own top-level helpers; `iggt` itself no longer uses sys.path
 
     d2 = _mod("detectron2")
     d2l = _mod("detectron2.layers")
@@ -87,6 +104,24 @@ def install():
     s2m.position_encoding = pe
 
 
+def uninstall():
+    """Forget the reference modules so that `import iggt` resolves to the product alias again."""
+    for k in [k for k in sys.modules if k == "iggt" or k.startswith("iggt.")]:
+        del sys.modules[k]
+    if REF_ROOT in sys.path:
+        sys.path.remove(REF_ROOT)
+
+
+def assert_reference(obj):
+    """Raise unless the class / module `obj` was loaded from the reference checkout (never from this repository)."""
+    import inspect
+
+    f = os.path.realpath(inspect.getsourcefile(obj) or "")
+    root = os.path.realpath(REF_ROOT) + os.sep
+    if not f.startswith(root):
+        raise RuntimeError(f"oracle/ref_shim: {obj!r} was loaded from {f}, not from the reference tree {root}")
+
+
 def build_reference_iggt(fast_init=True):
     """Construct the reference IGGT().eval().  fast_init skips trunc_normal_ (weights are
     overwritten by oracle.weights.fill_state_dict afterwards)."""
@@ -102,7 +137,11 @@ def build_reference_iggt(fast_init=True):
     try:
         from iggt.models.vggt import IGGT
 
+        assert_reference(IGGT)
         model = IGGT().eval()
+        for sub in (model.aggregator, model.camera_head, model.point_head, model.part_adaptor, model.part_head,
+                    model.aggregator.patch_embed, model.aggregator.frame_blocks[0].attn):
+            assert_reference(type(sub))
     finally:
         torch.nn.init.trunc_normal_ = saved
     return model

@@ -1,123 +1,9 @@
-"""Deterministic synthetic weights for the IGGT state-dict schema.
+"""Seeded synthetic weights / images used to pin the oracle (TEST INFRASTRUCTURE, see oracle/__init__.py).
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  No checkpoint is reachable (weights live on
-the HF hub, no network), so parity is pinned with seeded synthetic weights that are a pure
-function of (tensor name, shape, seed, mode) -- the same function fills the reference model
-in the build container (oracle/make_golden.py) and the HIP model on the GPU box.
-
-Modes
-  "default": LayerScale gamma = 0.01 in aggregator/camera blocks and 1.0 in the DINOv2
-             backbone, i.e. the reference's init scales (aggregator.py:63,153).
-  "stress" : gamma ~ U(0.5, 1.5) everywhere, so that an error in any attention / MLP kernel
-             reaches the outputs un-attenuated.
-All other tensors are drawn so that activations stay O(1) through the network.
+The generator itself lives in iggt_official_amd/synthetic.py (a dependency-free integer hash) because bench.py and
+__graft_entry__.smoke() feed the product model with the very same synthetic checkpoint the reference fixtures were
+produced with, and the product side may not import from oracle/.  This module re-exports it under the name the
+fixture generator and the tests have always used.
 """
-import zlib
-
-import torch
-
-
-def _name_seed(name: str, seed: int) -> int:
-    return (zlib.crc32(name.encode()) + 1000003 * seed) & 0x7FFFFFFF
-
-
-def hash_uniform(n: int, key: int, device="cpu") -> torch.Tensor:
-    """n reproducible U[0,1) fp32 samples from a counter-based integer hash.
-
-    Only exact integer ops (every intermediate < 2**62, so no int64 wrap) and one exact
-    int->float conversion: bit-identical on CPU and on the GPU, so the GPU box can synthesise the
-    1.3 B parameters on-device in milliseconds instead of streaming a CPU RNG."""
-    x = torch.arange(n, dtype=torch.int64, device=device)
-    x = (x * 747796405 + key) & 0xFFFFFFFF
-    x = x ^ (x >> 16)
-    x = (x * 0x45D9F3B) & 0xFFFFFFFF
-    x = x ^ (x >> 16)
-    x = (x * 0x45D9F3B) & 0xFFFFFFFF
-    x = x ^ (x >> 16)
-    return (x >> 8).to(torch.float32) * (1.0 / 16777216.0)
-
-
-_SQRT12 = 12.0 ** 0.5
-
-
-def make_tensor(name: str, shape, seed: int, mode: str, device="cpu") -> torch.Tensor:
-    """Synthetic value of state-dict entry `name`.  All draws are uniform (centred draws are scaled
-    to the requested standard deviation)."""
-    shape = tuple(shape)
-    leaf = name.split(".")[-1]
-    n = 1
-    for s_ in shape:
-        n *= s_
-    key = _name_seed(name, seed)
-
-    def randn(std=1.0):  # zero-mean uniform with the given std
-        return ((hash_uniform(n, key, device) - 0.5) * (_SQRT12 * std)).view(shape)
-
-    def uniform(lo, hi):
-        return (hash_uniform(n, key, device) * (hi - lo) + lo).view(shape)
-
-    def one_plus(std):
-        return ((hash_uniform(n, key, device) - 0.5) * (_SQRT12 * std) + 1.0).view(shape)
-
-    if leaf == "gamma":  # LayerScale
-        if mode == "stress":
-            return uniform(0.5, 1.5)
-        return torch.full(shape, 1.0 if ".patch_embed.blocks." in name else 0.01, device=device)
-    if leaf == "running_var":
-        return uniform(0.5, 1.5)
-    if leaf == "running_mean":
-        return randn(0.1)
-    if leaf in ("camera_token", "register_token", "cls_token", "register_tokens", "mask_token"):
-        return randn(1.0 if mode == "stress" else 0.02)
-    if leaf == "pos_embed":
-        return randn(0.2)
-    if leaf == "empty_pose_tokens":
-        return randn(0.1)
-    if leaf == "relative_position_bias_table":
-        return randn(0.5)
-    if leaf == "bias":
-        # norm-layer bias or linear/conv bias: small but non-zero
-        return randn(0.1)
-    if leaf == "weight":
-        if len(shape) == 1:  # LayerNorm / BatchNorm scale
-            return one_plus(0.1)
-        if ".resize_layers." in name and len(shape) == 4 and _is_conv_transpose(name):
-            # ConvTranspose2d weight is [in, out, kh, kw]; each output pixel sums over
-            # `in * ceil(k/stride)^2` taps.
-            fan = shape[0] * (4 if shape[2] == 4 and "part_adaptor" in name else 1)
-            return randn(fan ** -0.5)
-        fan_in = 1
-        for s_ in shape[1:]:
-            fan_in *= s_
-        return randn(fan_in ** -0.5)
-    raise KeyError(f"no synthetic rule for {name} {shape}")
-
-
-def _is_conv_transpose(name: str) -> bool:
-    # DPTHead / PartHead(inherited): resize_layers.0 (k4 s4) and .1 (k2 s2) are ConvTranspose2d
-    # (dpt_head.py:72-79).  SamProjector: resize_layers.0.0, .0.2 (k4 s2 p1) and .1.0 (k2 s2)
-    # (adaptor.py:152-166).
-    tail = name.split(".resize_layers.")[1]
-    if "part_adaptor" in name:
-        return tail.startswith(("0.0.", "0.2.", "1.0."))
-    return tail.startswith(("0.", "1."))
-
-
-def fill_state_dict(schema: dict, seed: int = 0, mode: str = "stress", device="cpu") -> dict:
-    """schema: {name: {"shape": [...], "dtype": "torch.float32"}} -> {name: tensor} for every
-    floating-point entry (integer buffers are left to the module that owns them)."""
-    out = {}
-    for name, meta in schema.items():
-        if not meta["dtype"].startswith("torch.float"):
-            continue
-        if name.startswith("track_head."):
-            # TrackHead only runs when query_points is given (vggt.py:220); out of scope.
-            continue
-        out[name] = make_tensor(name, meta["shape"], seed, mode, device)
-    return out
-
-
-def make_images(S: int, H: int, W: int, seed: int = 1, device="cpu") -> torch.Tensor:
-    """Synthetic views in [0,1): smooth low-frequency pattern + hash noise (bit-identical on CPU/GPU)."""
-    n = S * 3 * H * W
-    return hash_uniform(n, _name_seed("images", seed), device).view(S, 3, H, W)
+from iggt_official_amd.synthetic import (  # noqa: F401
+    _is_conv_transpose, _name_seed, fill_state_dict, hash_uniform, make_images, make_tensor)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Developer A/B builds of libiggt_hip.so (same ABI, one translation unit compiled with different flags) into
+probes/lib_alt/<name>.so; load one with IGGT_HIP_LIB=<path> (iggt_official_amd/_C.py).  Not part of the product."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from iggt_official_amd import build_ext  # noqa: E402
+
+VARIANTS = {
+    "attn_noslp": {"attention_v3.hip": ["-fno-slp-vectorize"]},
+    "attn_nopin": {"attention_v3.hip": ["-DIGGT_ATTN_NO_PIN"]},
+    "attn_nopin_noslp": {"attention_v3.hip": ["-DIGGT_ATTN_NO_PIN", "-fno-slp-vectorize"]},
+}
+
+
+def main():
+    build_ext.build(verbose=False)
+    out_dir = os.path.join(ROOT, "probes", "lib_alt")
+    os.makedirs(out_dir, exist_ok=True)
+    names = sys.argv[1:] or list(VARIANTS)
+    for name in names:
+        objs, procs = [], []
+        for src in build_ext.sources():
+            base = os.path.basename(src)
+            extra = VARIANTS[name].get(base)
+            if extra is None:
+                objs.append(os.path.join(build_ext.LIB_DIR, "obj", base[:-4] + ".o"))
+            else:
+                obj = os.path.join(out_dir, f"{name}_{base[:-4]}.o")
+                objs.append(obj)
+                procs.append(subprocess.Popen([build_ext.HIPCC] + build_ext.FLAGS + extra + ["-c", src, "-o", obj]))
+        for pr in procs:
+            assert pr.wait() == 0
+        lib = os.path.join(out_dir, name + ".so")
+        subprocess.check_call([build_ext.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+        print(lib)
+
+
+if __name__ == "__main__":
+    main()

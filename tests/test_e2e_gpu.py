@@ -3,7 +3,9 @@ modules on CPU fp32 (oracle/make_golden.py), same seeded weights and inputs.
 
 Tolerances.  north_star asks for 1e-3 relative on the outputs against the reference's fp32 CPU path.
   * default operand format, fp16 (iggt_official_amd/precision.py): gate = north_star's: relative l2 error < 1e-3 on
-    the four consumed token layers and on every output (max-abs error < 5e-3 of the output range);
+    the four consumed token layers and on every output -- both as ||d||/||ref|| and as ||d||/||ref - mean(ref)|| (the
+    head outputs of a random-init model are bias-dominated) -- and max-abs error < 1.5e-3
+    of the output range;
   * bf16 operands (the reference's own GPU mode, demo.py:193-195 autocast bf16, selectable): that mode itself
     deviates from fp32 by 7e-3 on tokens and 1e-3..1e-2 on outputs: gate 1e-2 / 3e-2.
 The per-kernel tests (test_kernels_gpu.py, test_kernels_f16_gpu.py, test_conv_gpu.py) hold each HIP kernel to its
@@ -30,7 +32,7 @@ def _restore_operand_dtype():
     precision.set_mean_compensation(old_comp)
 
 
-GATES = {"f16": (1e-3, 5e-3), "bf16": (1e-2, 3e-2)}   # (relative l2, max-abs / range)
+GATES = {"f16": (1e-3, 1.5e-3, 1e-3), "bf16": (1e-2, 3e-2, 3e-2)}   # (relative l2, max-abs / range, mean-centred l2)
 
 
 def _run(case, operands="f16"):
@@ -79,12 +81,12 @@ def test_forward_matches_reference(case, operands):
     assert len(pred["pose_enc"]) == 4 and pred["pose_enc"][-1].shape == (1, S, 9)
     assert all(v.dtype == torch.float32 for v in pred.values() if torch.is_tensor(v))
     # gates vs the fp32 CPU reference (see module docstring; measured values in profiles/r01_parity_report.json)
-    g_l2, g_max = GATES[operands]
+    g_l2, g_max, g_l2c = GATES[operands]
     for li in (4, 11, 17, 23):
         assert res[f"tokens_{li}"][1] < g_l2, (li, res[f"tokens_{li}"])
     for k in ("depth", "depth_conf", "world_points", "world_points_conf", "part_feat", "pose_enc"):
         if k in res:
-            assert res[k][1] < g_l2 and res[k][0] < g_max, (k, res[k])
+            assert res[k][1] < g_l2 and res[k][0] < g_max and res[k][2] < g_l2c, (k, res[k])
 
 
 def test_dino_backbone_tokens():
@@ -117,6 +119,35 @@ def test_chunked_heads_equal_unchunked():
         a = model.depth_head(tokens, images=images, patch_start_idx=psi, frames_chunk_size=None)
         b = model.depth_head(tokens, images=images, patch_start_idx=psi, frames_chunk_size=2)
         assert torch.allclose(a[0], b[0], rtol=rtol, atol=atol) and torch.allclose(a[1], b[1], rtol=rtol, atol=atol)
+
+
+def test_forward_under_caller_autocast_and_batched_scenes():
+    """demo.py:193-195 calls the model under autocast(bf16); the reference switches autocast OFF inside (vggt.py:189).
+    The outputs must be fp32 and identical to a call without autocast.  B = 2 scenes (reference vggt.py:149) equal the
+    two single-scene calls."""
+    from oracle import weights
+
+    g = load_golden("tiny_s2_56_stress")
+    m = g["meta"]
+    model = build_gpu_model(m["mode"], m["weight_seed"])
+    images = weights.make_images(m["S"], m["H"], m["W"], seed=m["image_seed"], device="cuda")
+    plain = model(images)
+    with torch.amp.autocast("cuda", dtype=torch.bfloat16):
+        auto = model(images)
+    for k, v in plain.items():
+        if k == "pose_enc":
+            assert all(a.dtype == torch.float32 and torch.equal(a, b) for a, b in zip(auto[k], v))
+        else:
+            assert auto[k].dtype == torch.float32 and torch.equal(auto[k], v), k
+    e = errors(auto["depth"], g["depth"])
+    assert e[1] < 1e-3, e
+    other = weights.make_images(m["S"], m["H"], m["W"], seed=77, device="cuda")
+    both = model(torch.stack([images, other], 0))
+    single = model(other)
+    assert both["depth"].shape == (2, m["S"], m["H"], m["W"], 1) and both["pose_enc"][-1].shape == (2, m["S"], 9)
+    assert torch.equal(both["depth"][0], plain["depth"][0]) and torch.equal(both["depth"][1], single["depth"][0])
+    assert torch.equal(both["part_feat"][1], single["part_feat"][0])
+    assert torch.equal(both["pose_enc"][-1][1], single["pose_enc"][-1][0])
 
 
 def test_no_cpu_fallback():

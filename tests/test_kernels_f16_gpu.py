@@ -135,11 +135,105 @@ def test_flash_attn_f16_peaked_and_wide_range(C):
     assert row[1] < 1e-3, row
 
 
-def test_flash_attn_f16_legacy_tiles_rejected(C):
+def test_flash_attn_unknown_tile_code_rejected(C):
+    """Only the production kernel's tile codes exist (the round-1 A/B kernels 128 / 256 / 512 are no longer built)."""
     qkv = _rand((64, 3 * 64), 1, 1.0, F16)
     o = torch.empty(64, 64, dtype=F16, device="cuda")
     with pytest.raises(C.HipExtensionError):
         C.flash_attn_d64(qkv, qkv[:, 64:], qkv[:, 128:], o, 1, 1, 64, 64, 0, 192, 0, 192, 0, 192, 0, 64, 0.125, 128)
+
+
+# ---------------------------------------------------------------------------------------------
+# Static-bound softmax (csrc/attention_v3.hip, iggt_flash_attn_static_*): q carries scale * log2(e), the shift is
+# |q|max |k|max per head.  The reference is the same fp64 softmax (base 2 on the pre-scaled q = scale ln 2).
+def _static_attn(C, qkv, B, H, Nq, Nk, N, tile, dtype):
+    Cdim = H * 64
+    x = qkv.view(B, N, 3, H, 64)
+    qn = x[:, :Nq, 0].float().norm(dim=-1).amax(dim=(0, 1))      # [H]
+    kn = x[:, :Nk, 1].float().norm(dim=-1).amax(dim=(0, 1))
+    qkmax = torch.zeros(32, device="cuda")
+    qkmax[:H], qkmax[16:16 + H] = qn, kn
+    flags = torch.full((B * H * ((Nq + 127) // 128) + 3,), 7, dtype=torch.int32, device="cuda")
+    o = torch.full((B * Nq, Cdim), float("nan"), dtype=dtype, device="cuda")
+    C.flash_attn_d64_static(qkv, qkv[:, Cdim:], qkv[:, 2 * Cdim:], o, B, H, Nq, Nk,
+                            N * 3 * Cdim, 3 * Cdim, N * 3 * Cdim, 3 * Cdim, N * 3 * Cdim, 3 * Cdim, Nq * Cdim, Cdim,
+                            qkmax, flags, tile)
+    q, k, v = x[:, :Nq, 0].transpose(1, 2), x[:, :Nk, 1].transpose(1, 2), x[:, :Nk, 2].transpose(1, 2)
+    ref = _attn_ref(q, k, v, 0.6931471805599453).transpose(1, 2).reshape(B * Nq, Cdim)
+    return o, ref, flags
+
+
+@pytest.mark.parametrize("dtype", [F16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Nq,Nk,tile", [(2, 16, 1374, 1374, 0), (1, 16, 4122, 4122, 0), (3, 4, 21, 21, 0),
+                                            (1, 16, 4122, 4122, 5256), (1, 16, 2748, 5496, 6256),
+                                            (2, 3, 1374, 1374, 6128), (1, 2, 300, 777, 6256), (1, 2, 300, 777, 5128),
+                                            (1, 1, 40, 64, 6256), (1, 2, 1000, 65, 6256), (1, 2, 500, 129, 6128)])
+def test_flash_attn_static_bound(C, dtype, B, H, Nq, Nk, tile):
+    Cdim = H * 64
+    N = max(Nq, Nk)
+    qkv = _rand((B * N, 3 * Cdim), 120 + Nq, 1.0, dtype)
+    qkv[:, :Cdim] *= 0.125 * 1.4426950408889634 * 1.3      # "pre-scaled" q: scores ~ N(0, (1.9 bit)^2)
+    o, ref, flags = _static_attn(C, qkv, B, H, Nq, Nk, N, tile, dtype)
+    assert not torch.isnan(o.float()).any()
+    mx, l2 = _relerr(o, ref)
+    name = "f16" if dtype == F16 else "bf16"
+    report(f"attn_static_{name}_B{B}_H{H}_{Nq}x{Nk}_t{tile}", dict(max=mx, l2=l2, flagged=int(flags[:-3].sum())))
+    if dtype == F16:
+        assert mx < 2e-3 and l2 < 5e-4, (mx, l2)
+    else:
+        assert mx < 1.5e-2 and l2 < 4e-3, (mx, l2)
+    assert torch.all(flags[-3:] == 7)                      # scratch beyond the work list untouched
+    assert int(flags[:-3].sum()) == 0                      # nothing needed the fallback on this benign input
+
+
+def test_flash_attn_static_bound_fallback_rows(C):
+    """Rows the static bound cannot serve in fp16 -- every score far below |q|max |k|max -- are flagged by their row sum and
+    recomputed by the online-max kernel: (a) query rows with a tiny norm next to rows with a large one (bound 40 bits,
+    their scores ~0), (b) a one-hot row, (c) ordinary rows.  All must meet the kernel tolerance."""
+    H, N = 2, 4000
+    Cdim = H * 64
+    qkv = _rand((N, 3 * Cdim), 133, 1.0, F16)
+    x = qkv.view(N, 3, H, 64)
+    x[:, 0] *= 0.125 * 1.4426950408889634
+    x[:, 0] *= 3.0                                 # |q^| ~ 4.3, |k| ~ 8  ->  bound ~ 35 bits per head
+    x[::3, 0] *= 0.01                              # every third query row: scores within +-0.1 bit, 35 bits below the bound
+    x[701, 1] = x[124, 0] / x[124, 0].float().norm(dim=-1, keepdim=True).half() * 8.0   # key 701 aligned with query 124
+    o, ref, flags = _static_attn(C, qkv, 1, H, N, N, N, 0, F16)
+    assert not torch.isnan(o.float()).any()
+    mx, l2 = _relerr(o, ref)
+    nflag = int(flags[:-3].sum())
+    report("attn_static_f16_fallback", dict(max=mx, l2=l2, flagged=nflag, tiles=int(flags.numel() - 3)))
+    assert nflag > 0                               # the fallback really ran
+    assert mx < 2e-3 and l2 < 5e-4, (mx, l2)
+    for r in (0, 3, 124, 125, 3999):
+        e = _relerr(o[r], ref[r])
+        assert e[1] < 1e-3, (r, e)
+
+
+def test_qknorm_rope_prescale_and_norm_maxima(C):
+    """q_scale is folded into q before the 16-bit rounding; qkmax receives the per-head maxima of the norms of the written
+    q and k vectors (the inputs of the static softmax bound)."""
+    from iggt_official_amd.layers.rope import RotaryPositionEmbedding2D
+
+    S, gh, gw, psi = 3, 5, 7, 5
+    P = psi + gh * gw
+    T = S * P
+    qkv = _rand((T, 3072), 150, 1.5, F16)
+    qw, qb, kw, kb = (_rand((64,), 51) * 0.3 + 1, _rand((64,), 52, 0.2), _rand((64,), 53) * 0.3 + 1,
+                      _rand((64,), 54, 0.2))
+    cos, sin = RotaryPositionEmbedding2D(100).tables(64, max(gh, gw), torch.device("cuda"))
+    plain, scaled = qkv.clone(), qkv.clone()
+    C.qknorm_rope(plain, plain, plain[:, 1024:], None, qw, qb, kw, kb, cos, sin, T, P, gw, psi, 1e-5)
+    qkmax = torch.full((32,), -1.0, device="cuda")
+    sc = 0.125 * C.LOG2E
+    C.qknorm_rope(scaled, scaled, scaled[:, 1024:], None, qw, qb, kw, kb, cos, sin, T, P, gw, psi, 1e-5, q_scale=sc,
+                  qkmax=qkmax)
+    assert torch.equal(scaled[:, 1024:], plain[:, 1024:])                      # k, v untouched by the scale
+    mx, l2 = _relerr(scaled[:, :1024], plain[:, :1024].double() * sc)
+    assert mx < 8e-4 and l2 < 4e-4, (mx, l2)                                   # one fp16 rounding apart
+    qn = scaled[:, :1024].float().view(T, 16, 64).norm(dim=-1).amax(0)
+    kn = scaled[:, 1024:2048].float().view(T, 16, 64).norm(dim=-1).amax(0)
+    assert torch.allclose(qkmax[:16], qn, rtol=1e-6, atol=0) and torch.allclose(qkmax[16:], kn, rtol=1e-6, atol=0)
 
 
 def test_layernorm_f16_out(C):

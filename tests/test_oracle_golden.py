@@ -55,3 +55,36 @@ def test_golden_weights_are_reproducible(schema):
     a = weights.make_tensor("depth_head.scratch.output_conv1.weight", (128, 256, 3, 3), 0, "stress")
     b = weights.make_tensor("depth_head.scratch.output_conv1.weight", (128, 256, 3, 3), 0, "stress")
     assert torch.equal(a, b) and abs(float(a.std()) * (256 * 9) ** 0.5 - 1.0) < 0.01
+
+
+def test_golden_recipe_imports_the_reference_and_reproduces_a_fixture(tmp_path):
+    """`python oracle/make_golden.py` must (a) resolve `iggt` to the REFERENCE checkout although this repository ships
+    a regular `iggt/` alias package of the product, and (b) reproduce a committed fixture bit for bit.  Runs in a
+    child process (the shim rebinds `iggt` in sys.modules).  Skipped where /root/reference does not exist."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import GOLDEN, ROOT
+    from oracle import ref_shim
+
+    if not ref_shim.available():
+        pytest.skip("no reference checkout on this machine")
+    probe = ("import sys; sys.path.insert(0, %r); import iggt.models.vggt as prod; "
+             "from oracle import ref_shim; ref_shim.install(); import iggt.models.vggt as v, iggt.heads.dpt_head as d; "
+             "print(prod.__file__); print(v.__file__); print(d.__file__)" % ROOT)
+    out = subprocess.run([sys.executable, "-c", probe], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    prod, ref_v, ref_d = out.stdout.strip().splitlines()[-3:]
+    assert prod.startswith(ROOT) and ref_v.startswith(ref_shim.REF_ROOT) and ref_d.startswith(ref_shim.REF_ROOT)
+
+    case = "tiny_s2_56_stress"
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_golden.py"), "--out", str(tmp_path), case],
+                         cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert run.returncode == 0, run.stderr[-2000:]
+    new = torch.load(os.path.join(str(tmp_path), case + ".pt"), weights_only=False)
+    old = torch.load(os.path.join(GOLDEN, case + ".pt"), weights_only=False)
+    assert set(new) == set(old)
+    for k, v in old.items():
+        if torch.is_tensor(v):
+            assert torch.equal(new[k], v), k

@@ -13,7 +13,8 @@ def test_state_dict_matches_reference_schema(schema):
     assert sorted(mine) == sorted(ref)
     for k in ref:
         assert mine[k] == ref[k], (k, mine[k], ref[k])
-    assert sum(1 for k in schema if k.startswith("track_head.")) == 394 or True  # out of scope, strict=False
+    # track_head.* (TrackHead, only used with query_points) is out of scope: present in the reference schema, absent here
+    assert sum(1 for k in schema if k.startswith("track_head.")) == len(schema) - len(ref) > 0
 
 
 def test_relative_position_buffers_match_reference():
