@@ -261,7 +261,7 @@ def main():
         ms = sum(r[0] for r in recs) / max(len(recs), 1)
         flops = 4.0 * Nq * Nk * C
         achieved = flops / (ms * 1e-3) / 1e12
-        kernel_label = _C.attn_kernel_label(1, 16, Nq, Nk, precision.operand_name())
+        kernel_label = _C.attn_kernel_label(1, 16, Nq, Nk, precision.operand_name(), static_bound=precision.static_softmax())
         traffic = PMC_TRAFFIC.get(f"{S}x{H}x{world}:{kernel_label}", {})
         line = {
             "metric": "views/sec (N-view 518^2 forward)",
@@ -277,7 +277,7 @@ def main():
             "dtype": precision.operand_name(),
             "data": data,
             "config": {"workload": f"{S} views @ {H}x{H}, IGGT forward (DINOv2 + 24x(frame,global) + camera/depth/"
-                                   "point heads), random-init weights, views sharded " + f"{S // world}/GPU",
+                                   "point heads), synthetic weights, views sharded " + f"{S // world}/GPU",
                        "views": S, "image_size": H, "tokens_per_view": P, "parallelism": f"view-shard x{world}"},
             "roofline": {"bound": "mfma", "kernel": kernel_label + " (global attention)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -287,6 +287,8 @@ def main():
                                                              "(profiles/attn_traffic.json)"),
                          "algorithmic_bytes_per_launch": 4.0 * Nk * C * 2,
                          "launches_timed": len(recs), "ms_per_launch": ms,
+                         "timed_region": ("static-bound kernel + its gated online-max pass over flagged tiles (none on this "
+                                          "input: ~10 us)") if precision.static_softmax() else "one kernel launch",
                          "flops_per_launch": flops},
         }
         if check is not None:

@@ -96,7 +96,7 @@ static int flash_attn_static_h16(int fmt, const void* q, const void* k, const vo
     const hipError_t e = hipMemsetAsync(flags, 0, nwork * sizeof(int), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     p.qkmax = qkmax; p.flags = flags;
-    p.static_min_l = fmt == FMT_F16 ? STATIC_MIN_L_F16 : STATIC_MIN_L_BF16;
+    p.static_min_l = fmt == FMT_F16 ? STATIC_MIN_L_PER_KEY_F16 * (float)Nk : STATIC_MIN_L_BF16;
     iggt_launch_flash_attn_v3(p, rows, code / 1000 - 4, fmt, true, (hipStream_t)stream);
     IGGT_CHECK_LAUNCH();
     p.qkmax = nullptr;   // gated dynamic pass: q already carries scale * log2 e

@@ -46,12 +46,14 @@ IGGT_DEVINL bf16x8 pack8h(const f32x16& s, int base) {
 // in fp16's normal range (smallest normal 6.1e-5 * 2^-8 = 2.4e-7 of the maximum, subnormals to 2.3e-10); the
 // shift cancels in O / l.  bf16 has fp32's exponent range and needs none.
 constexpr float P_SHIFT_F16 = 8.0f;
-// static-bound kernel: numerators 2^(s - c_h + 15) <= 2^15 (fp16 max 2^16); a row is accepted when its row sum is at least
-// 2^15 * 2^-11: the numerators that then fall below fp16's smallest subnormal (2^-24) carry < N * 2^-24 / 2^4 of the row's
-// mass (3e-4 at N = 44k in the worst case of a completely flat row, typically orders of magnitude less).  bf16 numerators
-// have fp32's exponent range: no shift, and the acceptance threshold only guards against fp32 underflow of l.
+// static-bound kernel: numerators 2^(s - c_h + 15) <= 2^15 (fp16 max 2^16).  A row is accepted when its row sum l is at
+// least Nk * 2^-13: numerators below fp16's smallest subnormal (2^-24) flush to zero and those between 2^-24 and 2^-14 are
+// rounded to a 2^-25 grid, so the mass a row can lose is < Nk * 2^-24 -- at most 2^-11 = 5e-4 of an accepted row's sum in
+// the contrived worst case (almost all keys just under the flush threshold), orders of magnitude less for any score
+// distribution that is not bimodal.  bf16 numerators have fp32's exponent range: no shift, and the acceptance threshold only
+// guards against fp32 underflow of l.
 constexpr float STATIC_SHIFT_F16 = 15.0f;
-constexpr float STATIC_MIN_L_F16 = 16.0f;
+constexpr float STATIC_MIN_L_PER_KEY_F16 = 1.0f / 8192.0f;
 constexpr float STATIC_MIN_L_BF16 = 1e-30f;
 
 }  // namespace iggt_attn

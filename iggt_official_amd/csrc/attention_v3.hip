@@ -33,7 +33,7 @@
 // (row sum) + 8 v_cvt_pk of VALU work beside 8 MFMAs (dynamic kernel: + 16 v_fma + 16 v_max + exchange + vote).
 // What the bound cannot give is a LOWER limit of a row's true maximum: a row whose scores all sit far below c_h ends
 // with numerators in fp16's subnormal range.  Such rows are detected after the loop by their row sum
-// (l_i < 2^SHIFT * STATIC_MIN_L) and their 256-row tile is flagged; the dynamic kernel (same file, gated on the flag
+// (l_i < Nk * 2^-13, attention_common.h) and their 256-row tile is flagged; the dynamic kernel (same file, gated on the flag
 // array) then recomputes exactly the flagged tiles.  With LayerNorm-ed q, k the slack is ~5 bits of the 29 available.
 #include "attention_common.h"
 #include "../../include/iggt_hip.h"
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     // static bound: the (negated) shift enters through the accumulator input of the first QK^T MFMA of a score block
     f32x16 cinit;
     if constexpr (STATIC) {
-        const float shift = p.qkmax[h] * p.qkmax[p.H + h] * 1.00002f + 1e-3f - (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
+        const float shift = p.qkmax[h] * p.qkmax[16 + h] * 1.00002f + 1e-3f - (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
 #pragma unroll
         for (int r = 0; r < 16; ++r) cinit[r] = -shift;
     } else {

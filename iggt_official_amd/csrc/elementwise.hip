@@ -156,9 +156,10 @@ struct QkParams {
 
 template <int FMT>
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
-    const int t = blockIdx.x;
     const int tid = threadIdx.x;
     const int which = tid >> 7, head = (tid >> 3) & 15, j = tid & 7;
+    float nmax2 = 0.f;   // largest squared norm this thread's (q|k, head) has produced (static softmax bound)
+    for (int t = blockIdx.x; t < p.T; t += gridDim.x) {   // grid-stride over tokens: one norm atomic per block, not per token
     const bf16_t* src = p.qkv + (long)t * p.ld_in + which * p.C + head * 64 + j * 8;
     const u32x4 raw = *reinterpret_cast<const u32x4*>(src);
     float x[8];
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = pack_h2<FMT>(y[2 * e], y[2 * e + 1]);
-    if (p.qkmax != nullptr) {   // |rounded vector|: 8 lanes of a head reduce; most tokens lose against the running maximum
+    if (p.qkmax != nullptr) {   // |rounded vector|^2, this lane's 8 elements (reduced over the head's 8 lanes after the loop)
         float n2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -215,12 +216,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
             n2 += a * a + b2 * b2;
         }
         n2 += __shfl_xor(n2, 1, 64); n2 += __shfl_xor(n2, 2, 64); n2 += __shfl_xor(n2, 4, 64);
-        if (j == 0) {
-            const float nrm = sqrtf(n2);
-            unsigned int* slot = reinterpret_cast<unsigned int*>(p.qkmax) + which * 16 + head;
-            const unsigned int bits = __builtin_bit_cast(unsigned int, nrm);
-            if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
-        }
+        nmax2 = fmaxf(nmax2, n2);
     }
     const int hgrp = head / p.hg, hin = head - hgrp * p.hg;
     bf16_t* dst = which ? (p.k_out + hgrp * p.kgs + (long)t * p.ldk + hin * 64) : (p.q_out + (long)t * p.ldq + head * 64);
@@ -230,6 +226,14 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
         const u32x4 vv = *reinterpret_cast<const u32x4*>(p.qkv + (long)t * p.ld_in + 2 * p.C + tid * 8);
         const int vh = tid >> 3, vg = vh / p.hg;
         *reinterpret_cast<u32x4*>(p.v_out + vg * p.vgs + (long)t * p.ldv + (vh - vg * p.hg) * 64 + (tid & 7) * 8) = vv;
+    }
+    }   // token loop
+    if (p.qkmax != nullptr && j == 0) {
+        // one atomic max per (block, q|k, head) on the bit pattern of a non-negative float; most blocks lose against the
+        // running maximum and skip the atomic (the plain load is only a filter: a stale value costs an atomic, never an error)
+        unsigned int* slot = reinterpret_cast<unsigned int*>(p.qkmax) + which * 16 + head;
+        const unsigned int bits = __builtin_bit_cast(unsigned int, sqrtf(nmax2));
+        if (bits > *reinterpret_cast<volatile unsigned int*>(slot)) atomicMax(slot, bits);
     }
 }
 
@@ -586,8 +590,9 @@ static int qknorm_rope_h16(int fmt, const void* qkv, long ld_in, void* q_out, lo
         const hipError_t e = hipMemsetAsync(qkmax, 0, 32 * sizeof(float), (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     }
-    if (fmt == FMT_F16) hipLaunchKernelGGL(qknorm_rope_kernel<FMT_F16>, dim3(T), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(qknorm_rope_kernel<FMT_BF16>, dim3(T), dim3(256), 0, (hipStream_t)stream, p);
+    const int grid = T < 4096 ? T : 4096;   // 2 resident rounds of 8 blocks per CU; each block strides over T / grid tokens
+    if (fmt == FMT_F16) hipLaunchKernelGGL(qknorm_rope_kernel<FMT_F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(qknorm_rope_kernel<FMT_BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
     return 0;
 }
