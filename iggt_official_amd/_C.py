@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 7
+ABI_VERSION = 9
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -63,6 +63,20 @@ _SIGNATURES = {
                              _c_int]
                             + [_c_int] * 24 + [_c_void_p],
     "iggt_bilinear_ac_nhwc_f32": [_c_void_p, _c_int, _c_void_p, _c_int] + [_c_int] * 6 + [_c_void_p] * 3,
+    "iggt_linear_f32": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p,
+                        _c_long, _c_int, _c_int, _c_int, _c_int, _c_void_p],
+    "iggt_attn_f32": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                      _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_float, _c_void_p],
+    "iggt_adaln_modulate_f32": [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_long,
+                                _c_int, _c_int, _c_float, _c_void_p],
+    "iggt_pose_update_f32": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p],
+    "iggt_conv1x1_c32_nchw_f32": [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_long, _c_int, _c_void_p],
+    "iggt_pose_to_extri_intri_f32": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
+    "iggt_unproject_depth_f32": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
+    "iggt_resize_bicubic_u8": [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int,
+                               _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p],
+    "iggt_u8hwc_to_f32chw": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                             _c_int, _c_float, _c_void_p],
     "iggt_write_special_tokens": [_c_void_p, _c_long, _c_long, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_void_p],
 }
@@ -171,6 +185,7 @@ def flash_attn_d64(q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
 
 
 LOG2E = 1.4426950408889634
+QKMAX_NUMEL = 32 + 32 * 4096   # iggt_qknorm_rope_*: 32 per-head norm maxima + scratch for the per-block partial maxima
 
 
 def flash_attn_d64_static(q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, qkmax, flags,
@@ -219,7 +234,7 @@ def layernorm(x0, w, b, out, eps, *, x1=None, rows=None, rows_in=0, rows_stride=
 def qknorm_rope(qkv, q_out, k_out, v_out, qw, qb, kw, kb, cos_t, sin_t, T, P, gw, patch_start, eps,
                 heads_per_group=0, k_group_stride=0, v_group_stride=0, q_scale=1.0, qkmax=None):
     _dev(qkv, q_out, k_out, v_out, qw, cos_t, qkmax)
-    assert qkmax is None or (qkmax.dtype == torch.float32 and qkmax.numel() >= 32 and qkmax.is_contiguous())
+    assert qkmax is None or (qkmax.dtype == torch.float32 and qkmax.numel() >= QKMAX_NUMEL and qkmax.is_contiguous())
     sfx = _h16(qkv, q_out, k_out) if v_out is None else _h16(qkv, q_out, k_out, v_out)
     assert qkv.shape[-1] == 3072
     fn = getattr(load(), "iggt_qknorm_rope_" + sfx)
@@ -371,3 +386,137 @@ def bilinear_ac_nhwc(x, y, xpart=None, ypart=None):
                                           _ptr(ypart), _stream())
     _check(rc, "iggt_bilinear_ac_nhwc_f32")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# fp32 small operators of the heads (csrc/smallops.hip)
+# ------------------------------------------------------------------------------------------------
+LIN_ACT = {None: 0, "none": 0, "gelu": 1, "relu": 2, "silu": 3, "sigmoid": 4}
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise HipExtensionError(f"{name} must be a contiguous fp32 tensor")
+    return t
+
+
+def linear_f32(x, weight, bias=None, *, act=None, gamma=None, res=None, out=None):
+    """act(x @ weight.T + bias) * gamma (+ res), exact fp32 (skinny problems: M = x rows is small).  x [M, K] (unit
+    column stride, any row stride), weight [N, K] contiguous, res / out [M, N]; res may be `out` itself."""
+    _dev(x, weight, bias, gamma, res, out)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    weight = _f32c(weight, "weight")
+    M, K = x.shape
+    N = weight.shape[0]
+    assert weight.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
+    if res is not None:
+        assert res.dtype == torch.float32 and res.shape == (M, N) and res.stride(1) == 1
+    rc = load().iggt_linear_f32(x.data_ptr(), x.stride(0), weight.data_ptr(), K, _ptr(_f32c(bias, "bias")),
+                                _ptr(_f32c(gamma, "gamma")), _ptr(res), 0 if res is None else res.stride(0),
+                                out.data_ptr(), out.stride(0), M, N, K, LIN_ACT[act], _stream())
+    _check(rc, "iggt_linear_f32")
+    return out
+
+
+def attn_f32(q, k, v, o, B, H, Nq, Nk, head_dim, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale):
+    """fp32 attention, token-major strided operands (see include/iggt_hip.h)."""
+    _dev(q, k, v, o)
+    for t in (q, k, v, o):
+        assert t.dtype == torch.float32
+    rc = load().iggt_attn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Nq, Nk, head_dim,
+                              q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, float(scale), _stream())
+    _check(rc, "iggt_attn_f32")
+    return o
+
+
+def adaln_modulate(x, shift, scale, gate, eps, out=None):
+    """gate * (LN_noaffine(x) * (1 + scale) + shift) + x; shift / scale / gate: column slices of one [rows, 3C] matrix."""
+    _dev(x, shift, scale, gate)
+    rows, C = x.shape
+    assert x.stride(1) == 1 and shift.stride(0) == scale.stride(0) == gate.stride(0) and shift.stride(1) == 1
+    if out is None:
+        out = torch.empty(rows, C, dtype=torch.float32, device=x.device)
+    rc = load().iggt_adaln_modulate_f32(x.data_ptr(), x.stride(0), shift.data_ptr(), scale.data_ptr(), gate.data_ptr(),
+                                        shift.stride(0), out.data_ptr(), out.stride(0), rows, C, float(eps), _stream())
+    _check(rc, "iggt_adaln_modulate_f32")
+    return out
+
+
+def pose_update(delta, pred, out, first):
+    _dev(delta, pred, out)
+    n = delta.shape[0]
+    assert delta.shape == (n, 9) and delta.is_contiguous() and pred.is_contiguous() and out.is_contiguous()
+    rc = load().iggt_pose_update_f32(delta.data_ptr(), pred.data_ptr(), out.data_ptr(), n, int(first), _stream())
+    _check(rc, "iggt_pose_update_f32")
+    return out
+
+
+def conv1x1_c32_nchw(x, w, b):
+    """x NHWC fp32 [N,H,W,>=32] contiguous -> [N,Cout,H,W] (Cout <= 8)."""
+    _dev(x, w, b)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    N, H, W, ld = x.shape
+    Cout = w.shape[0]
+    w = _f32c(w.reshape(Cout, -1), "w")
+    assert w.shape[1] == 32
+    y = torch.empty(N, Cout, H, W, dtype=torch.float32, device=x.device)
+    rc = load().iggt_conv1x1_c32_nchw_f32(x.data_ptr(), ld, w.data_ptr(), _ptr(_f32c(b, "b")), y.data_ptr(), H * W,
+                                          N * H * W, Cout, _stream())
+    _check(rc, "iggt_conv1x1_c32_nchw_f32")
+    return y
+
+
+def pose_to_extri_intri(pose, H, W, build_intrinsics=True):
+    """pose [..., 9] fp32 -> (extrinsics [..., 3, 4], intrinsics [..., 3, 3] or None)."""
+    _dev(pose)
+    p2 = pose.reshape(-1, 9).float().contiguous()
+    n = p2.shape[0]
+    extri = torch.empty(n, 3, 4, dtype=torch.float32, device=pose.device)
+    intri = torch.empty(n, 3, 3, dtype=torch.float32, device=pose.device) if build_intrinsics else None
+    rc = load().iggt_pose_to_extri_intri_f32(p2.data_ptr(), extri.data_ptr(), _ptr(intri), n, int(H), int(W), _stream())
+    _check(rc, "iggt_pose_to_extri_intri_f32")
+    lead = pose.shape[:-1]
+    return extri.view(*lead, 3, 4), (None if intri is None else intri.view(*lead, 3, 3))
+
+
+def unproject_depth(depth, extri, intri):
+    """depth [S,H,W] fp32, extri [S,3,4], intri [S,3,3] -> world points [S,H,W,3] fp32."""
+    _dev(depth, extri, intri)
+    depth, extri, intri = _f32c(depth, "depth"), _f32c(extri, "extri"), _f32c(intri, "intri")
+    S, H, W = depth.shape
+    out = torch.empty(S, H, W, 3, dtype=torch.float32, device=depth.device)
+    rc = load().iggt_unproject_depth_f32(depth.data_ptr(), extri.data_ptr(), intri.data_ptr(), out.data_ptr(), S, H, W,
+                                         _stream())
+    _check(rc, "iggt_unproject_depth_f32")
+    return out
+
+
+def resize_bicubic_u8(img, hbounds, hkk, vbounds, vkk, Ho, Wo):
+    """img uint8 [Hi,Wi,3] (device) -> uint8 [Ho,Wo,3], Pillow-exact bicubic; tables: int32 device tensors."""
+    _dev(img, hbounds, hkk, vbounds, vkk)
+    assert img.dtype == torch.uint8 and img.is_contiguous() and img.dim() == 3 and img.shape[2] == 3
+    for t in (hbounds, hkk, vbounds, vkk):
+        assert t.dtype == torch.int32 and t.is_contiguous()
+    Hi, Wi, _ = img.shape
+    tmp = torch.empty(Hi, Wo, 3, dtype=torch.uint8, device=img.device)
+    out = torch.empty(Ho, Wo, 3, dtype=torch.uint8, device=img.device)
+    rc = load().iggt_resize_bicubic_u8(img.data_ptr(), Hi, Wi, hbounds.data_ptr(), hkk.data_ptr(), hkk.shape[1],
+                                       vbounds.data_ptr(), vkk.data_ptr(), vkk.shape[1], tmp.data_ptr(), out.data_ptr(),
+                                       Ho, Wo, _stream())
+    _check(rc, "iggt_resize_bicubic_u8")
+    return out
+
+
+def u8hwc_to_f32chw(src, dst, crop_y, crop_x, pad_y, pad_x, h, w, pad_value=1.0):
+    """dst fp32 [3,Hd,Wd] <- src uint8 [Hs,Ws,3] window (crop, h x w) at (pad_y, pad_x), / 255, rest = pad_value."""
+    _dev(src, dst)
+    assert src.dtype == torch.uint8 and src.is_contiguous() and dst.dtype == torch.float32 and dst.is_contiguous()
+    rc = load().iggt_u8hwc_to_f32chw(src.data_ptr(), src.shape[0], src.shape[1], dst.data_ptr(), dst.shape[1], dst.shape[2],
+                                     crop_y, crop_x, pad_y, pad_x, h, w, float(pad_value), _stream())
+    _check(rc, "iggt_u8hwc_to_f32chw")
+    return dst

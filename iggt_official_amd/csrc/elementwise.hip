@@ -148,11 +148,13 @@ struct QkParams {
     int hg;
     long kgs, vgs;
     // static-bound softmax (attention_v3.hip): q is written pre-multiplied by q_scale (softmax scale * log2 e; 1 = off) and
-    // the largest Euclidean norms of the ROUNDED q and k head vectors are accumulated into qkmax[h] / qkmax[16 + h]
-    // (atomic max on the bit pattern of a non-negative float; nullptr = off).  The buffer is zeroed by the entry point.
+    // the largest Euclidean norms of the ROUNDED q and k head vectors end up in qkmax[h] / qkmax[16 + h] (nullptr = off):
+    // every block writes the maxima of its tokens to qkmax[32 + 32 * block ...], qkmax_reduce_kernel folds them.
+    // (A first version used one atomic max per block and (q|k, head): 131k atomics on 32 addresses cost 70 us per call.)
     float q_scale;
     float* qkmax;
 };
+constexpr int QK_MAX_BLOCKS = 4096;
 
 template <int FMT>
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
@@ -228,12 +230,21 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
         *reinterpret_cast<u32x4*>(p.v_out + vg * p.vgs + (long)t * p.ldv + (vh - vg * p.hg) * 64 + (tid & 7) * 8) = vv;
     }
     }   // token loop
-    if (p.qkmax != nullptr && j == 0) {
-        // one atomic max per (block, q|k, head) on the bit pattern of a non-negative float; most blocks lose against the
-        // running maximum and skip the atomic (the plain load is only a filter: a stale value costs an atomic, never an error)
-        unsigned int* slot = reinterpret_cast<unsigned int*>(p.qkmax) + which * 16 + head;
-        const unsigned int bits = __builtin_bit_cast(unsigned int, sqrtf(nmax2));
-        if (bits > *reinterpret_cast<volatile unsigned int*>(slot)) atomicMax(slot, bits);
+    if (p.qkmax != nullptr && j == 0) p.qkmax[32 + 32 * (long)blockIdx.x + which * 16 + head] = sqrtf(nmax2);
+}
+
+// qkmax[s] = max over blocks of the per-block maxima written by qknorm_rope_kernel (s = q|k * 16 + head).
+__global__ __launch_bounds__(1024) void qkmax_reduce_kernel(float* qkmax, int nblocks) {
+    __shared__ float sm[32][33];
+    const int s = threadIdx.x & 31, g = threadIdx.x >> 5;   // 32 slots x 32 row groups
+    float m = 0.f;
+    for (int b = g; b < nblocks; b += 32) m = fmaxf(m, qkmax[32 + 32 * (long)b + s]);
+    sm[g][s] = m;
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int i = 1; i < 32; ++i) m = fmaxf(m, sm[i][s]);
+        qkmax[s] = m;
     }
 }
 
@@ -586,14 +597,14 @@ static int qknorm_rope_h16(int fmt, const void* qkv, long ld_in, void* q_out, lo
         p.hg = heads_per_group; p.kgs = k_group_stride; p.vgs = v_group_stride;
     }
     p.q_scale = q_scale; p.qkmax = qkmax;
-    if (qkmax != nullptr) {
-        const hipError_t e = hipMemsetAsync(qkmax, 0, 32 * sizeof(float), (hipStream_t)stream);
-        if (e != hipSuccess) return (int)e;
-    }
-    const int grid = T < 4096 ? T : 4096;   // 2 resident rounds of 8 blocks per CU; each block strides over T / grid tokens
+    const int grid = T < QK_MAX_BLOCKS ? T : QK_MAX_BLOCKS;   // each block strides over T / grid tokens
     if (fmt == FMT_F16) hipLaunchKernelGGL(qknorm_rope_kernel<FMT_F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(qknorm_rope_kernel<FMT_BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
+    if (qkmax != nullptr) {
+        hipLaunchKernelGGL(qkmax_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, qkmax, grid);
+        IGGT_CHECK_LAUNCH();
+    }
     return 0;
 }
 

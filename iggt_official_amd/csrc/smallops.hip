@@ -1,0 +1,380 @@
+// fp32 "small" operators of the heads: everything the reference computes in fp32 on a handful of tokens or as a cheap
+// per-pixel map, where a 16-bit MFMA GEMM would cost accuracy and a tensor-library call costs a launch each.
+//
+//   iggt_linear_f32          exact-fp32 nn.Linear for skinny problems (M = S camera tokens, squeeze-excite vectors, ...):
+//                            v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: bit-for-bit an fmaf chain), one 32 x 32 output
+//                            tile per workgroup, K split over its 8 waves, weights streamed once -- the op is bound by the
+//                            weight bytes (4 B per parameter), not by the matrix pipe.
+//                            reference: camera_head.py:83-154 (trunk Linears, embed_pose, poseLN_modulation, pose_branch),
+//                            window_sa.py:26-37 (ChannelAttention 1x1 convs on a pooled vector)
+//   iggt_attn_f32            softmax(scale q k^T) v in fp32, head dim 32 / 64 / 128, token-major strided operands:
+//                            camera trunk attention over the S views (16 heads x 128, camera_head.py:124 -> layers/block.py),
+//                            CrossAttention of the part head (8 heads x 32, heads/block.py:212-242)
+//   iggt_adaln_modulate_f32  gate * (LayerNorm_noaffine(x) * (1 + scale) + shift) + x           (camera_head.py:130-134)
+//   iggt_pose_update_f32     pred (+)= delta; activate_pose (T, quat linear; FoV relu)           (camera_head.py:144-151, head_act.py:9-37)
+//   iggt_conv1x1_c32_nchw_f32  last 1x1 conv of the part head, NHWC in -> NCHW out               (part_head.py:128,240-243)
+//   iggt_pose_to_extri_intri_f32 / iggt_unproject_depth_f32   pose encoding -> [R|t], K; depth -> world points
+//                            (utils/pose_enc.py:65-130, utils/rotation.py:14-44, utils/geometry.py:151-268)
+#include "common.h"
+#include "gemm_common.h"
+#include "../../include/iggt_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Linear, fp32 MFMA.  A = x rows (lane -> row m0 + lane % 32, k pair member lane / 32), B = W rows (= columns of W^T).
+struct LinParams {
+    const float* x; long ldx;
+    const float* w; long ldw;
+    const float* bias; const float* gamma;
+    const float* res; long ldr;
+    float* out; long ldo;
+    int M, N, K, act;
+};
+
+IGGT_DEVINL float lin_act(float v, int act) {
+    switch (act) {
+        case 1: return gelu_erf(v);
+        case 2: return fmaxf(v, 0.f);
+        case 3: return v / (1.f + __expf(-v));          // SiLU
+        case 4: return 1.f / (1.f + __expf(-v));        // sigmoid
+        default: return v;
+    }
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(512) void linear_f32_kernel(const LinParams p) {
+    __shared__ float red[8][32][33];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int r = lane & 31, h = lane >> 5;
+    int mr = m0 + r, nr = n0 + r;
+    mr = mr < p.M ? mr : p.M - 1;
+    nr = nr < p.N ? nr : p.N - 1;
+    const float* xrow = p.x + (long)mr * p.ldx;
+    const float* wrow = p.w + (long)nr * p.ldw;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // k chunks of 16 interleaved over the 8 waves: lane half h owns k = 16 c + 8 h + [0, 8)
+    const int nchunks = (p.K + 15) >> 4;
+    for (int c = wave; c < nchunks; c += 8) {
+        const int k0 = c * 16 + 8 * h;
+        float xa[8], wb[8];
+        if (ALIGNED && c * 16 + 16 <= p.K) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow + k0), x1 = *reinterpret_cast<const f32x4*>(xrow + k0 + 4);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow + k0), w1 = *reinterpret_cast<const f32x4*>(wrow + k0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xa[e] = x0[e]; xa[4 + e] = x1[e]; wb[e] = w0[e]; wb[4 + e] = w1[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = k0 + e < p.K;
+                xa[e] = ok ? xrow[k0 + e] : 0.f;
+                wb[e] = ok ? wrow[k0 + e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[e], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][mfma32_row(i, lane)][r] = acc[i];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int idx = e * 512 + tid, row = idx >> 5, col = idx & 31;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[w][row][col];
+        const int m = m0 + row, n = n0 + col;
+        if (m < p.M && n < p.N) {
+            if (p.bias) v += p.bias[n];
+            v = lin_act(v, p.act);
+            if (p.gamma) v *= p.gamma[n];
+            if (p.res) v += p.res[(long)m * p.ldr + n];
+            p.out[(long)m * p.ldo + n] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention, fp32.  256 threads = 64 query rows x 4 threads; thread q of a row owns the float4 chunks 4 i + q of the head
+// dimension (so that the four threads of a row read 64 contiguous bytes of a K / V row: conflict-free LDS broadcast).
+struct AttnF32Params {
+    const float* q; const float* k; const float* v; float* o;
+    long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;   // elements; head h at column offset h * D
+    int B, H, Nq, Nk;
+    float scale_log2;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32Params p) {
+    constexpr int NC = D / 16;                 // float4 chunks per thread
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    float* Ks = smf;
+    float* Vs = smf + 64 * D;
+    const int tid = threadIdx.x, row = tid >> 2, qq = tid & 3;
+    const int h = blockIdx.y, b = blockIdx.z;
+    int qr = blockIdx.x * 64 + row;
+    const bool valid = qr < p.Nq;
+    qr = valid ? qr : p.Nq - 1;
+    const float* qp = p.q + (long)b * p.q_bs + (long)qr * p.q_rs + h * D;
+    f32x4 qv[NC], o[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        qv[i] = *reinterpret_cast<const f32x4*>(qp + 4 * (4 * i + qq));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { qv[i][e] *= p.scale_log2; o[i][e] = 0.f; }
+    }
+    float m = -INFINITY, l = 0.f;
+    const float* kb = p.k + (long)b * p.k_bs + h * D;
+    const float* vb = p.v + (long)b * p.v_bs + h * D;
+    for (int t0 = 0; t0 < p.Nk; t0 += 64) {
+        __syncthreads();
+        for (int i = tid; i < 64 * (D / 4); i += 256) {
+            const int kr = i / (D / 4), c4 = i - kr * (D / 4);
+            int kg = t0 + kr;
+            kg = kg < p.Nk ? kg : p.Nk - 1;
+            *reinterpret_cast<f32x4*>(Ks + kr * D + 4 * c4) = *reinterpret_cast<const f32x4*>(kb + (long)kg * p.k_rs + 4 * c4);
+            *reinterpret_cast<f32x4*>(Vs + kr * D + 4 * c4) = *reinterpret_cast<const f32x4*>(vb + (long)kg * p.v_rs + 4 * c4);
+        }
+        __syncthreads();
+        const int nk = (p.Nk - t0) < 64 ? (p.Nk - t0) : 64;
+        for (int j0 = 0; j0 < nk; j0 += 4) {
+            float s[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const f32x4 kk = *reinterpret_cast<const f32x4*>(Ks + (j0 + e) * D + 4 * (4 * i + qq));
+                    d += qv[i][0] * kk[0] + qv[i][1] * kk[1] + qv[i][2] * kk[2] + qv[i][3] * kk[3];
+                }
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                s[e] = (j0 + e < nk) ? d : -INFINITY;
+            }
+            const float mn = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), m);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);   // m = -inf on the first step: exp2(-inf) = 0
+            m = mn;
+            float pe[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pe[e] = __builtin_amdgcn_exp2f(s[e] - mn);
+            l = l * alpha + (pe[0] + pe[1]) + (pe[2] + pe[3]);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[i][c] *= alpha;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 vv = *reinterpret_cast<const f32x4*>(Vs + (j0 + e) * D + 4 * (4 * i + qq));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[i][c] += pe[e] * vv[c];
+                }
+            }
+        }
+    }
+    if (valid) {
+        const float inv = 1.f / l;
+        float* op = p.o + (long)b * p.o_bs + (long)qr * p.o_rs + h * D;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            f32x4 w;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w[c] = o[i][c] * inv;
+            *reinterpret_cast<f32x4*>(op + 4 * (4 * i + qq)) = w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// adaLN modulation: out = gate * (LN(x) * (1 + scale) + shift) + x, LN without affine, one block per row.
+struct AdaLnParams {
+    const float* x; long ldx;
+    const float* shift; const float* scale; const float* gate; long ldm;
+    float* out; long ldo;
+    int rows, C; float eps;
+};
+
+__global__ __launch_bounds__(256) void adaln_modulate_kernel(const AdaLnParams p) {
+    __shared__ float sh[2][4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* x = p.x + (long)row * p.ldx;
+    float s = 0.f, s2 = 0.f;
+    for (int c = tid; c < p.C; c += 256) { const float v = x[c]; s += v; }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) sh[0][tid >> 6] = s;
+    __syncthreads();
+    const float mean = (sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]) / p.C;
+    for (int c = tid; c < p.C; c += 256) { const float d = x[c] - mean; s2 += d * d; }
+    s2 = wave_sum(s2);
+    if ((tid & 63) == 0) sh[1][tid >> 6] = s2;
+    __syncthreads();
+    const float rstd = rsqrtf((sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]) / p.C + p.eps);
+    const long mo = (long)row * p.ldm;
+    for (int c = tid; c < p.C; c += 256) {
+        const float ln = (x[c] - mean) * rstd;
+        p.out[(long)row * p.ldo + c] = p.gate[mo + c] * (ln * (1.f + p.scale[mo + c]) + p.shift[mo + c]) + x[c];
+    }
+}
+
+// pred = first ? delta : pred + delta;  out = activate_pose(pred): T (0..2) and quaternion (3..6) linear, FoV (7, 8) relu.
+__global__ void pose_update_kernel(const float* delta, float* pred, float* out, int n, int first) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 9) return;
+    const float v = first ? delta[i] : pred[i] + delta[i];
+    pred[i] = v;
+    out[i] = (i % 9) >= 7 ? fmaxf(v, 0.f) : v;
+}
+
+// 1x1 convolution from 32 NHWC channels to Cout <= 8 NCHW planes.
+__global__ __launch_bounds__(256) void conv1x1_c32_nchw_kernel(const float* x, long ldx, const float* w, const float* b,
+                                                                float* y, long hw, long npix, int Cout) {
+    __shared__ float ws[8 * 32 + 8];
+    for (int i = threadIdx.x; i < Cout * 32; i += 256) ws[i] = w[i];
+    if (threadIdx.x < Cout) ws[8 * 32 + threadIdx.x] = b ? b[threadIdx.x] : 0.f;
+    __syncthreads();
+    const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= npix) return;
+    f32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(x + pix * ldx + 4 * i);
+    const long n = pix / hw, r = pix - n * hw;
+    for (int c = 0; c < Cout; ++c) {
+        float a = ws[8 * 32 + c];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a += v[i][e] * ws[c * 32 + 4 * i + e];
+        y[(n * Cout + c) * hw + r] = a;
+    }
+}
+
+// pose encoding [n][9] = (T, quat xyzw, fov_h, fov_w) -> extrinsics [n][3][4] = [R | T], intrinsics [n][3][3]
+__global__ void pose_to_extri_intri_kernel(const float* pose, float* extri, float* intri, int n, float H, float W) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* pe = pose + 9 * i;
+    const float qi = pe[3], qj = pe[4], qk = pe[5], qr = pe[6];
+    const float two_s = 2.0f / (qi * qi + qj * qj + qk * qk + qr * qr);
+    float* e = extri + 12 * i;
+    e[0] = 1 - two_s * (qj * qj + qk * qk); e[1] = two_s * (qi * qj - qk * qr);     e[2] = two_s * (qi * qk + qj * qr);     e[3] = pe[0];
+    e[4] = two_s * (qi * qj + qk * qr);     e[5] = 1 - two_s * (qi * qi + qk * qk); e[6] = two_s * (qj * qk - qi * qr);     e[7] = pe[1];
+    e[8] = two_s * (qi * qk - qj * qr);     e[9] = two_s * (qj * qk + qi * qr);     e[10] = 1 - two_s * (qi * qi + qj * qj); e[11] = pe[2];
+    if (intri != nullptr) {
+        float* k = intri + 9 * i;
+        const float fy = (H / 2.0f) / tanf(pe[7] / 2.0f), fx = (W / 2.0f) / tanf(pe[8] / 2.0f);
+        k[0] = fx; k[1] = 0.f; k[2] = W / 2; k[3] = 0.f; k[4] = fy; k[5] = H / 2; k[6] = 0.f; k[7] = 0.f; k[8] = 1.f;
+    }
+}
+
+// world = R^T (cam - t),  cam = ((u - cu) d / fu, (v - cv) d / fv, d); fp64 inside like the reference's numpy path.
+__global__ __launch_bounds__(256) void unproject_depth_kernel(const float* depth, const float* extri, const float* intri,
+                                                               float* out, int S, int H, int W) {
+    const long hw = (long)H * W;
+    const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= S * hw) return;
+    const int s = (int)(pix / hw);
+    const long r = pix - s * hw;
+    const int vy = (int)(r / W), ux = (int)(r - (long)vy * W);
+    const float* e = extri + 12 * s;
+    const float* k = intri + 9 * s;
+    const double d = depth[pix];
+    const double xc = ((double)ux - (double)k[2]) * d / (double)k[0];
+    const double yc = ((double)vy - (double)k[5]) * d / (double)k[4];
+    // the reference stacks the camera coordinates as float32 before the rigid transform (geometry.py:266)
+    const double cx = (double)(float)xc, cy = (double)(float)yc, cz = (double)(float)d;
+    const double tx = -((double)e[0] * e[3] + (double)e[4] * e[7] + (double)e[8] * e[11]);
+    const double ty = -((double)e[1] * e[3] + (double)e[5] * e[7] + (double)e[9] * e[11]);
+    const double tz = -((double)e[2] * e[3] + (double)e[6] * e[7] + (double)e[10] * e[11]);
+    out[3 * pix + 0] = (float)(cx * e[0] + cy * e[4] + cz * e[8] + tx);
+    out[3 * pix + 1] = (float)(cx * e[1] + cy * e[5] + cz * e[9] + ty);
+    out[3 * pix + 2] = (float)(cx * e[2] + cy * e[6] + cz * e[10] + tz);
+}
+
+}  // namespace
+
+extern "C" int iggt_linear_f32(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* gamma,
+                               const float* res, long ldr, float* out, long ldo, int M, int N, int K, int act,
+                               void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 4) return -1;
+    if (ldx < K || ldw < K || ldo < N || (res && ldr < N)) return -2;
+    LinParams p{x, ldx, w, ldw, bias, gamma, res, ldr, out, ldo, M, N, K, act};
+    const dim3 grid((N + 31) / 32, (M + 31) / 32), block(512);
+    const bool aligned = (ldx % 4 == 0) && (ldw % 4 == 0) && (((uintptr_t)x | (uintptr_t)w) % 16 == 0);
+    if (aligned) hipLaunchKernelGGL(linear_f32_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(linear_f32_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int iggt_attn_f32(const float* q, const float* k, const float* v, float* o, int B, int H, int Nq, int Nk,
+                             int head_dim, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
+                             long o_rs, float scale, void* stream) {
+    if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return -1;
+    if ((q_rs | k_rs | v_rs | o_rs | q_bs | k_bs | v_bs | o_bs) % 4) return -2;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16) return -2;
+    AttnF32Params p{q, k, v, o, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, B, H, Nq, Nk, scale * 1.4426950408889634f};
+    const dim3 grid((Nq + 63) / 64, H, B), block(256);
+    const size_t lds = 2 * 64 * (size_t)head_dim * sizeof(float);
+    if (head_dim == 32) hipLaunchKernelGGL(attn_f32_kernel<32>, grid, block, lds, (hipStream_t)stream, p);
+    else if (head_dim == 64) hipLaunchKernelGGL(attn_f32_kernel<64>, grid, block, lds, (hipStream_t)stream, p);
+    else if (head_dim == 128) {
+        static bool attr = false;
+        if (!attr) {
+            const hipError_t e = hipFuncSetAttribute((const void*)attn_f32_kernel<128>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            attr = true;
+        }
+        hipLaunchKernelGGL(attn_f32_kernel<128>, grid, block, lds, (hipStream_t)stream, p);
+    } else return -3;
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int iggt_adaln_modulate_f32(const float* x, long ldx, const float* shift, const float* scale, const float* gate,
+                                       long ldm, float* out, long ldo, int rows, int C, float eps, void* stream) {
+    if (rows <= 0 || C <= 0) return -1;
+    AdaLnParams p{x, ldx, shift, scale, gate, ldm, out, ldo, rows, C, eps};
+    hipLaunchKernelGGL(adaln_modulate_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, p);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int iggt_pose_update_f32(const float* delta, float* pred, float* out, int n, int first, void* stream) {
+    if (n <= 0) return -1;
+    hipLaunchKernelGGL(pose_update_kernel, dim3((n * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, delta, pred, out, n,
+                       first);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int iggt_conv1x1_c32_nchw_f32(const float* x, long ldx, const float* w, const float* b, float* y, long hw,
+                                         long npix, int Cout, void* stream) {
+    if (npix <= 0 || hw <= 0 || Cout <= 0 || Cout > 8 || ldx < 32 || (ldx % 4) || (npix % hw)) return -1;
+    hipLaunchKernelGGL(conv1x1_c32_nchw_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       w, b, y, hw, npix, Cout);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int iggt_pose_to_extri_intri_f32(const float* pose, float* extri, float* intri, int n, int H, int W,
+                                            void* stream) {
+    if (n <= 0 || H <= 0 || W <= 0) return -1;
+    hipLaunchKernelGGL(pose_to_extri_intri_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, pose, extri, intri, n,
+                       (float)H, (float)W);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int iggt_unproject_depth_f32(const float* depth, const float* extri, const float* intri, float* out, int S,
+                                        int H, int W, void* stream) {
+    if (S <= 0 || H <= 0 || W <= 0) return -1;
+    const long npix = (long)S * H * W;
+    hipLaunchKernelGGL(unproject_depth_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, depth,
+                       extri, intri, out, S, H, W);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}

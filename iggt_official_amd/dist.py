@@ -52,6 +52,7 @@ class ViewShard:
         self.kv_groups = g if self.world > 1 else 1
         self._streams: List = []
         self._events: List = []
+        self.ctl = None   # graphs.SegmentedGraph while a forward is being captured: collectives become eager steps
 
     def local_views(self, S: int) -> Tuple[int, int]:
         return view_partition(S, self.world, self.rank)
@@ -70,8 +71,12 @@ class ViewShard:
         """kv_local [T_l, 2C] (contiguous) -> [world*T_l, 2C], rank-major = view-major token order."""
         assert kv_local.is_contiguous()
         out = self._buf("kv_all", (self.world * kv_local.shape[0], kv_local.shape[1]), kv_local)
-        self._gather(out, kv_local)
+        self._step(lambda: self._gather(out, kv_local))
         return out
+
+    def _step(self, fn):
+        """Run a collective now; under graph capture it is recorded as an eager step between two graph segments."""
+        return fn() if self.ctl is None else self.ctl.eager(fn)
 
     def _flat(self) -> bool:
         """RCCL ("nccl"): one flat all_gather_into_tensor.  gloo (host-logic tests, the single-GPU two-rank test) lacks the
@@ -115,8 +120,8 @@ class ViewShard:
 
     def all_gather_rows(self, x_local: torch.Tensor) -> torch.Tensor:
         """[n_l, ...] -> [world*n_l, ...] (camera tokens, small outputs)."""
-        x_local = x_local.contiguous()
-        out = torch.empty((self.world * x_local.shape[0],) + tuple(x_local.shape[1:]), dtype=x_local.dtype,
-                          device=x_local.device)
-        self._gather(out, x_local)
+        src = self._buf("rows_in", tuple(x_local.shape), x_local)
+        src.copy_(x_local)
+        out = self._buf("rows_out", (self.world * x_local.shape[0],) + tuple(x_local.shape[1:]), x_local)
+        self._step(lambda: self._gather(out, src))
         return out

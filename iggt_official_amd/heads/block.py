@@ -2,15 +2,14 @@
 
 The reference runs xformers' memory-efficient attention when available and an explicit
 softmax(q k^T * scale) v otherwise (block.py:132-136, 225-229); both are the same function.  Here the
-attention core is `F.scaled_dot_product_attention` on the GPU in fp32 (head dim 32: the head-dim-64
-HIP flash kernel does not apply; DESIGN.md lists a d=32 variant as next); the q/k/v/proj Linear layers run on the
-split-bf16 HIP GEMM (heads/tokenops.py).  qk_norm / rope are never
-enabled by IGGT (part_head.py:74,83; window_sa.py:193) and are not built.
+attention core is the fp32 HIP kernel `iggt_attn_f32` (head dim 32, token-major operands read in place from the
+projection outputs: no head transposes); the q/k/v/proj Linear layers run on the split-bf16 HIP GEMM
+(heads/tokenops.py).  qk_norm / rope are never enabled by IGGT (part_head.py:74,83; window_sa.py:193) and are not built.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
+from .. import _C
 from . import tokenops as tk
 
 
@@ -28,9 +27,11 @@ class Attention(nn.Module):
 
     def forward(self, x, xpos=None):
         B, N, C = x.shape
-        qkv = tk.linear(self.qkv, x).view(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
-        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], scale=self.scale)
-        return tk.linear(self.proj, o.transpose(1, 2).reshape(B, N, C))
+        qkv = tk.linear(self.qkv, x).view(B * N, 3 * C)
+        o = torch.empty(B, N, C, dtype=torch.float32, device=x.device)
+        _C.attn_f32(qkv, qkv[:, C:], qkv[:, 2 * C:], o, B, self.num_heads, N, N, self.head_dim,
+                    N * 3 * C, 3 * C, N * 3 * C, 3 * C, N * 3 * C, 3 * C, N * C, C, self.scale)
+        return tk.linear(self.proj, o)
 
 
 MemEffAttention = Attention
@@ -53,12 +54,14 @@ class CrossAttention(nn.Module):
 
     def forward(self, query, key, value, qpos=None, kpos=None):
         B, Nq, C = query.shape
-        h, d = self.num_heads, self.head_dim
-        q = tk.linear(self.projq, query).view(B, Nq, h, d).transpose(1, 2)
-        k = tk.linear(self.projk, key).view(B, key.shape[1], h, d).transpose(1, 2)
-        v = tk.linear(self.projv, value).view(B, value.shape[1], h, d).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
-        return tk.linear(self.proj, o.transpose(1, 2).reshape(B, Nq, C))
+        Nk = key.shape[1]
+        q = tk.linear(self.projq, query)     # [B, Nq, C] fp32, head h in columns [h d, (h + 1) d)
+        k = tk.linear(self.projk, key)
+        v = tk.linear(self.projv, value)
+        o = torch.empty(B, Nq, C, dtype=torch.float32, device=q.device)
+        _C.attn_f32(q, k, v, o, B, self.num_heads, Nq, Nk, self.head_dim, Nq * C, C, Nk * C, C, Nk * C, C, Nq * C, C,
+                    self.scale)
+        return tk.linear(self.proj, o)
 
 
 class MemEffCrossAttention(CrossAttention):

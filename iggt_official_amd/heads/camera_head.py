@@ -1,32 +1,50 @@
-"""Camera head -- reference iggt/heads/camera_head.py:19-162.
+"""Camera head -- reference iggt/heads/camera_head.py:19-162, on HIP kernels.
 
-4 refinement iterations of a 4-block transformer trunk (dim 2048, 16 heads x 128, LayerScale 0.01)
-over the S camera tokens of the last aggregator layer, with adaLN modulation from the previous pose
-estimate.  < 0.1 % of the forward FLOPs (S tokens!), so round 1 keeps it on plain PyTorch-ROCm fp32
-ops ("keep in PyTorch first"); its state-dict names match
-the reference (trunk blocks reuse iggt_official_amd.layers.blocks.Block as parameter holders).
-With sharded views the camera tokens of all ranks are all-gathered first (dist.ViewShard).
+4 refinement iterations of a 4-block transformer trunk (dim 2048, 16 heads x 128, LayerScale 0.01) over the S camera
+tokens of the last aggregator layer, with adaLN modulation from the previous pose estimate.  The reference runs it in
+fp32 (autocast off, vggt.py:189) and so does this: every Linear is the exact-fp32 MFMA kernel `iggt_linear_f32` (the
+problem is S rows against 1.6 GB of fp32 weights per iteration -- weight-bandwidth bound, a 16-bit operand format would
+buy nothing but error), the attention over the S views is `iggt_attn_f32` (head dim 128), LayerNorms are
+`iggt_layernorm_f32` with fp32 output, the adaLN modulation and the pose accumulation + activation are one small kernel
+each (csrc/smallops.hip).  State-dict names match the reference (trunk blocks reuse layers.blocks.Block as parameter
+holders).  With sharded views the camera tokens of all ranks are all-gathered first (dist.ViewShard).
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
-from ..layers.blocks import Block, Mlp
-from .head_act import activate_pose
+from .. import _C
+from ..layers.blocks import Block, LayerScale, Mlp
 
 
 def modulate(x, shift, scale):
     return x * (1 + scale) + shift
 
 
-def _block_torch(blk: Block, x):
-    """x += g1*proj(sdpa(qkv(norm1 x))); x += g2*fc2(gelu(fc1(norm2 x)))  -- fp32 eager (block.py:105-106)."""
+def _p(t):
+    return None if t is None else t.detach()
+
+
+def _ln(norm: nn.LayerNorm, x):
+    out = torch.empty_like(x)
+    _C.layernorm(x, _p(norm.weight), _p(norm.bias), out, norm.eps)
+    return out
+
+
+def _block_hip(blk: Block, x):
+    """x [N, C] fp32 -> x + g1 * proj(attn(qkv(norm1 x))), then + g2 * fc2(gelu(fc1(norm2 .)))  (block.py:105-106);
+    updates x in place."""
     a = blk.attn
-    B, N, C = x.shape
-    qkv = a.qkv(blk.norm1(x)).view(B, N, 3, a.num_heads, a.head_dim).permute(2, 0, 3, 1, 4)
-    o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, N, C)
-    x = x + blk.ls1(a.proj(o))
-    return x + blk.ls2(blk.mlp.fc2(F.gelu(blk.mlp.fc1(blk.norm2(x)))))
+    N, C = x.shape
+    H, d = a.num_heads, a.head_dim
+    qkv = _C.linear_f32(_ln(blk.norm1, x), _p(a.qkv.weight), _p(a.qkv.bias))
+    ao = torch.empty(N, C, dtype=torch.float32, device=x.device)
+    _C.attn_f32(qkv, qkv[:, C:], qkv[:, 2 * C:], ao, 1, H, N, N, d, 0, 3 * C, 0, 3 * C, 0, 3 * C, 0, C, a.scale)
+    g1 = _p(blk.ls1.gamma) if isinstance(blk.ls1, LayerScale) else None
+    g2 = _p(blk.ls2.gamma) if isinstance(blk.ls2, LayerScale) else None
+    _C.linear_f32(ao, _p(a.proj.weight), _p(a.proj.bias), gamma=g1, res=x, out=x)
+    hid = _C.linear_f32(_ln(blk.norm2, x), _p(blk.mlp.fc1.weight), _p(blk.mlp.fc1.bias), act="gelu")
+    _C.linear_f32(hid, _p(blk.mlp.fc2.weight), _p(blk.mlp.fc2.bias), gamma=g2, res=x, out=x)
+    return x
 
 
 class CameraHead(nn.Module):
@@ -35,6 +53,8 @@ class CameraHead(nn.Module):
         super().__init__()
         if pose_encoding_type != "absT_quaR_FoV":
             raise ValueError(f"Unsupported camera encoding type: {pose_encoding_type}")
+        if (trans_act, quat_act, fl_act) != ("linear", "linear", "relu"):
+            raise NotImplementedError("the HIP pose kernel implements IGGT's activations (linear, linear, relu)")
         self.target_dim = 9
         self.trans_act, self.quat_act, self.fl_act = trans_act, quat_act, fl_act
         self.trunk_depth = trunk_depth
@@ -51,18 +71,32 @@ class CameraHead(nn.Module):
     def forward(self, aggregated_tokens_list, num_iterations=4, camera_tokens=None):
         """camera_tokens [B, S, 2048] overrides the slice of the last layer (multi-GPU: gathered tokens)."""
         tokens = aggregated_tokens_list[-1][:, :, 0] if camera_tokens is None else camera_tokens
-        return self.trunk_fn(self.token_norm(tokens.float()), num_iterations)
+        if not tokens.is_cuda:
+            raise _C.HipExtensionError("CameraHead runs on HIP kernels only (no CPU fallback)")
+        B, S, C = tokens.shape
+        per_scene = [self.trunk_fn(_ln(self.token_norm, tokens[b].float().contiguous()), num_iterations)
+                     for b in range(B)]
+        return [torch.stack([ps[i] for ps in per_scene], 0) for i in range(num_iterations)]
 
     def trunk_fn(self, pose_tokens, num_iterations):
-        B, S, C = pose_tokens.shape
-        pred, outs = None, []
-        for _ in range(num_iterations):
-            inp = self.empty_pose_tokens.expand(B, S, -1) if pred is None else pred.detach()
-            shift, scale, gate = self.poseLN_modulation(self.embed_pose(inp)).chunk(3, dim=-1)
-            x = gate * modulate(self.adaln_norm(pose_tokens), shift, scale) + pose_tokens
+        """pose_tokens [S, C] fp32 (already token_norm-ed) -> list of num_iterations activated encodings [S, 9]."""
+        S, C = pose_tokens.shape
+        dev = pose_tokens.device
+        pred = torch.empty(S, 9, dtype=torch.float32, device=dev)
+        mod_lin = self.poseLN_modulation[1]
+        outs = []
+        for it in range(num_iterations):
+            inp = self.empty_pose_tokens.detach().float().view(1, 9).expand(S, 9).contiguous() if it == 0 else pred
+            # embed_pose, then the SiLU that opens poseLN_modulation fused into its epilogue
+            emb = _C.linear_f32(inp, _p(self.embed_pose.weight), _p(self.embed_pose.bias), act="silu")
+            mod = _C.linear_f32(emb, _p(mod_lin.weight), _p(mod_lin.bias))                       # [S, 3C] = shift | scale | gate
+            x = _C.adaln_modulate(pose_tokens, mod[:, :C], mod[:, C:2 * C], mod[:, 2 * C:], self.adaln_norm.eps)
             for blk in self.trunk:
-                x = _block_torch(blk, x)
-            delta = self.pose_branch.fc2(F.gelu(self.pose_branch.fc1(self.trunk_norm(x))))
-            pred = delta if pred is None else pred + delta
-            outs.append(activate_pose(pred, trans_act=self.trans_act, quat_act=self.quat_act, fl_act=self.fl_act))
+                x = _block_hip(blk, x)
+            hid = _C.linear_f32(_ln(self.trunk_norm, x), _p(self.pose_branch.fc1.weight), _p(self.pose_branch.fc1.bias),
+                                act="gelu")
+            delta = _C.linear_f32(hid, _p(self.pose_branch.fc2.weight), _p(self.pose_branch.fc2.bias))
+            out = torch.empty(S, 9, dtype=torch.float32, device=dev)
+            _C.pose_update(delta, pred, out, first=(it == 0))
+            outs.append(out)
         return outs

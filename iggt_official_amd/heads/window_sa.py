@@ -80,8 +80,8 @@ class CAB(nn.Module):
         t = co.run(p0, x, act=3, ldy=mid_pad)           # GELU fused; channels [mid, mid_pad) stay zero
         y = co.run(p2, t)
         g = y.mean(dim=(1, 2))                           # AdaptiveAvgPool2d(1) over the whole frame
-        g = F.relu(F.linear(g, ca[1].weight.flatten(1), ca[1].bias))
-        g = torch.sigmoid(F.linear(g, ca[3].weight.flatten(1), ca[3].bias))
+        g = _C.linear_f32(g, ca[1].weight.detach().flatten(1), ca[1].bias.detach(), act="relu")      # squeeze  (fp32 HIP)
+        g = _C.linear_f32(g, ca[3].weight.detach().flatten(1), ca[3].bias.detach(), act="sigmoid")   # excite
         return y * g[:, None, None, :]
 
 

@@ -212,7 +212,7 @@ class Block(nn.Module):
         # with the per-head maxima of |q| and |k|; not for the head-group pipelined gather (per-group launches)
         static = (self.attn.qk_norm and precision.static_softmax() and H == 16
                   and getattr(kv_gather, "kv_groups", 1) <= 1)
-        qkmax = ws.get("qkmax", (32,), torch.float32, dev) if static else None
+        qkmax = ws.get("qkmax", (_C.QKMAX_NUMEL,), torch.float32, dev) if static else None
         sk = dict(q_scale=self.attn.scale * _C.LOG2E, qkmax=qkmax) if static else {}
         if self.attn.qk_norm:
             assert rope_geom is not None
@@ -235,7 +235,7 @@ class Block(nn.Module):
                 kv_local = ws.get("kv_local", (T, 2 * C), dt, dev)
                 _C.qknorm_rope(qkv, qkv, kv_local, kv_local[:, C:], *qk_args, **sk)
                 if static:   # keys of the other ranks: the data-independent bound instead of this rank's maximum
-                    qkmax[16:].copy_(pk["k_bound"])
+                    qkmax[16:32].copy_(pk["k_bound"])
                 kv_all = gather(kv_local)
                 assert batch == 1
                 k_src, v_src, kv_rs, Nk, k_bs = kv_all, kv_all[:, C:], 2 * C, kv_all.shape[0], 0

@@ -30,8 +30,9 @@ except Exception:  # pragma: no cover
     class PyTorchModelHubMixin:  # type: ignore
         pass
 
-from .. import _C
+from .. import _C, precision
 from ..dist import ViewShard
+from ..graphs import GraphCache
 from ..heads.adaptor import SamProjector
 from ..heads.camera_head import CameraHead
 from ..heads.dpt_head import DPTHead
@@ -40,9 +41,48 @@ from .aggregator import Aggregator
 
 
 class _Base(nn.Module, PyTorchModelHubMixin):
+    def _init_runtime(self):
+        self._graphs_on = False
+        self._gcache = GraphCache()
+        # packed weights are rebuilt when parameters change; captured graphs hold pointers to the old packs
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._gcache.reset())
+
     def set_view_shard(self, shard: Optional[ViewShard]):
         self.aggregator.shard = shard
+        self._gcache.reset()
         return self
+
+    def enable_graphs(self, on: bool = True):
+        """Replay the forward as hipGraph segments (iggt_official_amd/graphs.py): one capture per input shape, then a
+        handful of host calls per forward instead of ~2 500 launches -- what the per-rank forward of a multi-GPU run
+        needs.  Outputs then live in static buffers that the next call overwrites (clone what must survive); call
+        `reset_graphs()` after changing parameters in place."""
+        self._graphs_on = bool(on)
+        if not on:
+            self._gcache.reset()
+        return self
+
+    def reset_graphs(self):
+        self._gcache.reset()
+
+    def _dispatch(self, images, run):
+        """run(images[1,S,3,H,W]) -> dict, eagerly or through the graph cache."""
+        if not self._graphs_on:
+            return run(images)
+        shard = self.aggregator.shard
+        key = (tuple(images.shape), precision.operand_name(), precision.static_softmax(),
+               precision.mean_compensation(), None if shard is None else (shard.rank, shard.world))
+
+        def fwd(static_in, ctl):
+            if shard is not None:
+                shard.ctl = ctl
+            try:
+                return run(static_in)
+            finally:
+                if shard is not None:
+                    shard.ctl = None
+
+        return self._gcache.run(key, images, fwd)
 
     def _common(self, images, query_points):
         if query_points is not None:
@@ -89,6 +129,15 @@ class VGGT(_Base):
         self.depth_head = DPTHead(dim_in=2 * embed_dim, output_dim=2, activation="exp", conf_activation="expp1",
                                   use_point_feat=False)
         self.track_head = None
+        self._init_runtime()
+
+    def _run(self, images):
+        tokens, psi = self.aggregator(images)
+        pred = {"pose_enc": self._camera(tokens)}
+        pred["depth"], pred["depth_conf"] = self.depth_head(tokens, images=images, patch_start_idx=psi)
+        pred["world_points"], pred["world_points_conf"] = self.point_head(tokens, images=images, patch_start_idx=psi)
+        pred["images"] = images
+        return pred
 
     @torch.no_grad()
     def forward(self, images, query_points=None):
@@ -96,13 +145,7 @@ class VGGT(_Base):
             images = self._common(images, query_points)
             if images.shape[0] != 1:
                 return self._scenes(images, query_points)
-            tokens, psi = self.aggregator(images)
-            pred = {"pose_enc": self._camera(tokens)}
-            pred["depth"], pred["depth_conf"] = self.depth_head(tokens, images=images, patch_start_idx=psi)
-            pred["world_points"], pred["world_points_conf"] = self.point_head(tokens, images=images,
-                                                                              patch_start_idx=psi)
-            pred["images"] = images
-        return pred
+            return self._dispatch(images, self._run)
 
 
 class IGGT(_Base):
@@ -120,6 +163,22 @@ class IGGT(_Base):
         self.part_head = PartHead(dim_in=2 * embed_dim, output_dim=8, activation="norm")
         assert part_on_invalid_grid in ("raise", "skip")
         self.part_on_invalid_grid = part_on_invalid_grid
+        self._init_runtime()
+
+    def _run(self, images):
+        H, W = images.shape[-2:]
+        part_ok = (H % 28 == 0) and (W % 28 == 0)
+        tokens, psi = self.aggregator(images)
+        pred = {"pose_enc": self._camera(tokens)}
+        pred["depth"], pred["depth_conf"] = self.depth_head(tokens, images=images, patch_start_idx=psi)
+        pts, conf, point_feat = self.point_head(tokens, images=images, patch_start_idx=psi)
+        pred["world_points"], pred["world_points_conf"] = pts, conf
+        if part_ok:
+            pyramid, _ = self.part_adaptor(tokens, images=images, patch_start_idx=psi)
+            pred["part_feat"] = self.part_head(list(pyramid.values()), point_feature=point_feat, images=images,
+                                               patch_start_idx=psi)
+        pred["images"] = images
+        return pred
 
     @torch.no_grad()
     def forward(self, images, query_points=None):
@@ -135,14 +194,4 @@ class IGGT(_Base):
             if not part_ok and self.part_on_invalid_grid == "raise":
                 raise ValueError(f"IGGT part head needs H, W multiples of 28, got {H}x{W} (the reference fails in "
                                  "window_sa.py:73); construct IGGT(part_on_invalid_grid='skip') for geometry only")
-            tokens, psi = self.aggregator(images)
-            pred = {"pose_enc": self._camera(tokens)}
-            pred["depth"], pred["depth_conf"] = self.depth_head(tokens, images=images, patch_start_idx=psi)
-            pts, conf, point_feat = self.point_head(tokens, images=images, patch_start_idx=psi)
-            pred["world_points"], pred["world_points_conf"] = pts, conf
-            if part_ok:
-                pyramid, _ = self.part_adaptor(tokens, images=images, patch_start_idx=psi)
-                pred["part_feat"] = self.part_head(list(pyramid.values()), point_feature=point_feat, images=images,
-                                                   patch_start_idx=psi)
-            pred["images"] = images
-        return pred
+            return self._dispatch(images, self._run)

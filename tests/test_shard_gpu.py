@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, kv_groups, ret):
+def _worker(rank, world, port, case, kv_groups, graphs, ret):
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
@@ -47,8 +47,15 @@ def _worker(rank, world, port, case, kv_groups, ret):
         model.set_view_shard(shard)
         v0, v1 = shard.local_views(m["S"])
         images = weights.make_images(m["S"], m["H"], m["W"], seed=m["image_seed"], device="cuda")[v0:v1]
-        pred = model(images)
+        if graphs:   # hipGraph segments with the collectives as eager steps between them (iggt_official_amd/graphs.py)
+            model.enable_graphs(True)
+            model(images)                       # capture
+        pred = model(images)                    # graphs: replay
         torch.cuda.synchronize()
+        if graphs:
+            seg = next(iter(model._gcache._graphs.values()))[1]
+            assert seg.num_segments == 24 + 1 + 1, seg.num_segments   # 24 K/V gathers + 1 camera-token gather
+            model.enable_graphs(False)
         res = {}
         for k in ("depth", "depth_conf", "world_points", "world_points_conf", "part_feat"):
             if k in g:
@@ -59,12 +66,13 @@ def _worker(rank, world, port, case, kv_groups, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,kv_groups", [("tiny_s2_56_stress", 4), ("tiny_s2_56_stress", 1)])
-def test_two_rank_sharded_forward_matches_reference(case, kv_groups):
+@pytest.mark.parametrize("case,kv_groups,graphs", [("tiny_s2_56_stress", 4, False), ("tiny_s2_56_stress", 1, False),
+                                                   ("tiny_s2_56_stress", 1, True)])
+def test_two_rank_sharded_forward_matches_reference(case, kv_groups, graphs):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), case, kv_groups, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), case, kv_groups, graphs, ret), nprocs=world, join=True)
     assert set(ret.keys()) == {0, 1}
     for rank, res in ret.items():
         for k, l2 in res.items():
