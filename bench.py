@@ -276,7 +276,8 @@ def main():
         ms = sum(r[0] for r in recs) / max(len(recs), 1)
         flops = 4.0 * Nq * Nk * C
         achieved = flops / (ms * 1e-3) / 1e12
-        kernel_label = _C.attn_kernel_label(1, 16, Nq, Nk, precision.operand_name(), static_bound=precision.static_softmax())
+        kernel_label = _C.attn_kernel_label(1, 16, Nq, Nk, precision.operand_name(), static_bound=precision.static_softmax(),
+                                            with_part_ws=True)
         traffic = PMC_TRAFFIC.get(f"{S}x{H}x{world}:{kernel_label}", {})
         line = {
             "metric": "views/sec (N-view 518^2 forward)",

@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -35,11 +35,25 @@ _SIGNATURES = {
                                 _c_float, _c_int, _c_void_p],
     "iggt_flash_attn_static_bf16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                                         _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
-                                        _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p],
+                                        _c_void_p, _c_void_p, _c_int, _c_void_p, _c_long, _c_int, _c_void_p],
     "iggt_flash_attn_static_f16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                                        _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
-                                       _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p],
-    "iggt_flash_attn_d64_kernel_name": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_char_p, _c_int],
+                                       _c_void_p, _c_void_p, _c_int, _c_void_p, _c_long, _c_int, _c_void_p],
+    "iggt_flash_attn_static_ws_bytes": [_c_int, _c_int, _c_int, _c_int],
+    "iggt_flash_attn_static_partial_bf16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                                                _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
+                                                _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
+    "iggt_flash_attn_static_partial_f16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                                               _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
+                                               _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
+    "iggt_flash_attn_static_combine_bf16_d64": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                                _c_int, _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _c_long, _c_long,
+                                                _c_long, _c_long, _c_long, _c_void_p, _c_int, _c_int, _c_void_p],
+    "iggt_flash_attn_static_combine_f16_d64": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                               _c_int, _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _c_long, _c_long,
+                                               _c_long, _c_long, _c_long, _c_void_p, _c_int, _c_int, _c_void_p],
+    "iggt_flash_attn_d64_kernel_name": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_char_p,
+                                        _c_int],
     "iggt_layernorm_f32": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long,
                            _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p],
     "iggt_qknorm_rope_bf16": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long,
@@ -82,6 +96,9 @@ _SIGNATURES = {
 }
 
 
+_LONG_RETURN = {"iggt_flash_attn_static_ws_bytes"}
+
+
 class HipExtensionError(RuntimeError):
     pass
 
@@ -107,7 +124,7 @@ def load():
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = _c_int
+        fn.restype = _c_long if name in _LONG_RETURN else _c_int
     v = lib.iggt_hip_abi_version()
     if v != ABI_VERSION:
         raise HipExtensionError(f"libiggt_hip ABI {v} != expected {ABI_VERSION}; rebuild")
@@ -189,26 +206,57 @@ QKMAX_NUMEL = 32 + 32 * 4096   # iggt_qknorm_rope_*: 32 per-head norm maxima + s
 
 
 def flash_attn_d64_static(q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, qkmax, flags,
-                          q_rows_per_wg=0):
-    """Static-bound attention (include/iggt_hip.h): q carries scale * log2(e), qkmax fp32 [32] = per-head norm bounds of
-    q (0..15) and k (16..31) as written by qknorm_rope(..., q_scale, qkmax); flags int32 scratch."""
-    _dev(q, k, v, o, qkmax, flags)
+                          q_rows_per_wg=0, part_ws=None):
+    """Static-bound attention (include/iggt_hip.h): q carries scale * log2(e), qkmax fp32 [>= 32] = per-head norm bounds of
+    q (0..15) and k (16..31) as written by qknorm_rope(..., q_scale, qkmax); flags int32 scratch; part_ws: optional byte
+    scratch (static_attn_ws_bytes) that lets small grids split the keys into ranges."""
+    _dev(q, k, v, o, qkmax, flags, part_ws)
     sfx = _h16(q, k, v, o)
     assert qkmax.dtype == torch.float32 and qkmax.numel() >= 32 and qkmax.is_contiguous()
     assert flags.dtype == torch.int32 and flags.is_contiguous()
+    assert part_ws is None or (part_ws.dtype == torch.uint8 and part_ws.is_contiguous())
     fn = getattr(load(), f"iggt_flash_attn_static_{sfx}_d64")
     rc = fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Nq, Nk,
             q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, qkmax.data_ptr(), flags.data_ptr(), flags.numel(),
-            q_rows_per_wg, _stream())
+            _ptr(part_ws), 0 if part_ws is None else part_ws.numel(), q_rows_per_wg, _stream())
     _check(rc, f"iggt_flash_attn_static_{sfx}_d64")
     return o
 
 
-def attn_kernel_label(B, H, Nq, Nk, operand_name, static_bound=False, q_rows_per_wg=0):
+def static_attn_ws_bytes(B, H, Nq, Nk):
+    """Bytes of partial workspace with which flash_attn_d64_static may split the keys of this shape (0: it never would)."""
+    return int(load().iggt_flash_attn_static_ws_bytes(B, H, Nq, Nk))
+
+
+def flash_attn_d64_static_partial(q, k, v, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, qkmax, o_part, l_part, slot0,
+                                  ksplit, q_rows_per_wg=0):
+    """One key segment -> partial slots [slot0, slot0 + ksplit) (include/iggt_hip.h)."""
+    _dev(q, k, v, qkmax, o_part, l_part)
+    sfx = _h16(q, k, v, o_part)
+    assert l_part.dtype == torch.float32 and o_part.is_contiguous() and l_part.is_contiguous()
+    fn = getattr(load(), f"iggt_flash_attn_static_partial_{sfx}_d64")
+    rc = fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
+            qkmax.data_ptr(), o_part.data_ptr(), l_part.data_ptr(), slot0, ksplit, q_rows_per_wg, _stream())
+    _check(rc, f"iggt_flash_attn_static_partial_{sfx}_d64")
+
+
+def flash_attn_d64_static_combine(o_part, l_part, nslots, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
+                                  o_bs, o_rs, flags, q_rows_per_wg=0):
+    """Fold nslots partial slots into o + flagged-tile fallback over the full key set (include/iggt_hip.h)."""
+    _dev(o_part, l_part, q, k, v, o, flags)
+    sfx = _h16(q, k, v, o, o_part)
+    fn = getattr(load(), f"iggt_flash_attn_static_combine_{sfx}_d64")
+    rc = fn(o_part.data_ptr(), l_part.data_ptr(), nslots, q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Nq,
+            Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, flags.data_ptr(), flags.numel(), q_rows_per_wg, _stream())
+    _check(rc, f"iggt_flash_attn_static_combine_{sfx}_d64")
+    return o
+
+
+def attn_kernel_label(B, H, Nq, Nk, operand_name, static_bound=False, q_rows_per_wg=0, with_part_ws=False):
     """Name of the attention kernel instantiation the dispatcher launches for this shape (for reports)."""
-    buf = ctypes.create_string_buffer(128)
-    rc = load().iggt_flash_attn_d64_kernel_name(B, H, Nq, int(operand_name in ("f16", "fp16")), int(static_bound),
-                                                q_rows_per_wg, buf, 128)
+    buf = ctypes.create_string_buffer(160)
+    rc = load().iggt_flash_attn_d64_kernel_name(B, H, Nq, Nk, int(operand_name in ("f16", "fp16")), int(static_bound),
+                                                int(with_part_ws), q_rows_per_wg, buf, 160)
     _check(rc, "iggt_flash_attn_d64_kernel_name")
     return buf.value.decode()
 

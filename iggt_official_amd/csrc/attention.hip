@@ -60,7 +60,29 @@ int fill_params(AttnParams& p, const void* q, const void* k, const void* v, void
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs;
     p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.scale_log2 = 1.f; p.qtiles = 0; p.qkmax = nullptr; p.flags = nullptr; p.static_min_l = 0.f;
+    p.ksplit = 0; p.slot0 = 0; p.o_part = nullptr; p.l_part = nullptr;
     return 0;
+}
+
+// Key ranges for a grid too small to fill the chip with 256-row tiles (cost in units of one full-length 256-row workgroup
+// at 2 workgroups per CU: rounds / s; the unsplit alternative -- 128-row tiles -- measures ~1.0 at the per-rank shape of an
+// 8-GPU run).  0: one pass.
+int choose_ksplit(int B, int H, int Nq, int Nk) {
+    const long w256 = (long)B * H * ((Nq + 255) / 256), slots = (long)device_cus() * 2;
+    if (w256 * 10 >= slots * 12) return 0;
+    const int nmt = (Nk + 127) / 128;
+    int best = 0;
+    double best_cost = 0.92;
+    for (int s = 2; s <= 8; ++s) {
+        if (nmt / s < 8) break;
+        const double cost = (double)((w256 * s + slots - 1) / slots) / s + 0.02;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
+long part_ws_bytes(int slots, int B, int H, int Nq) {
+    return (long)slots * B * Nq * ((long)H * 64 * 2 + (long)H * 4);
 }
 
 }  // namespace
@@ -79,15 +101,74 @@ static int flash_attn_h16(int fmt, const void* q, const void* k, const void* v, 
     return 0;
 }
 
-// Static-bound launch: the fast kernel over every query tile, then the dynamic kernel over the tiles it flagged.
+// One pass of the static-bound kernel over a key segment into partial slots [slot0, slot0 + ksplit).
+static int flash_attn_static_partial_h16(int fmt, const void* q, const void* k, const void* v, int B, int H, int Nq, int Nk,
+                                         long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
+                                         const float* qkmax, void* o_part, float* l_part, int slot0, int ksplit,
+                                         int q_rows_per_wg, void* stream) {
+    AttnParams p;
+    const int rc = fill_params(p, q, k, v, o_part, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, 0, 64);
+    if (rc) return rc;
+    if (qkmax == nullptr || o_part == nullptr || l_part == nullptr || H > 16 || ksplit < 1 || slot0 < 0) return -5;
+    const int code = q_rows_per_wg ? q_rows_per_wg : 6256;
+    if (!valid_code(code)) return -3;
+    const int kvm = code / 1000 - 4;
+    if ((Nk + 64 * kvm - 1) / (64 * kvm) < ksplit) return -7;
+    p.qkmax = qkmax; p.ksplit = ksplit; p.slot0 = slot0; p.o_part = (bf16_t*)o_part; p.l_part = l_part;
+    iggt_launch_flash_attn_v3(p, code % 1000, kvm, fmt, true, (hipStream_t)stream);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+// Fold nslots partial results into o, flag the rows below the acceptance threshold and redo their tiles (online-max kernel
+// over all Nk keys).
+static int flash_attn_static_combine_h16(int fmt, const void* o_part, const float* l_part, int nslots, const void* q,
+                                         const void* k, const void* v, void* o, int B, int H, int Nq, int Nk, long q_bs,
+                                         long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs, long o_rs,
+                                         int* flags, int flags_len, int q_rows_per_wg, void* stream) {
+    AttnParams p;
+    const int rc = fill_params(p, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs);
+    if (rc) return rc;
+    if (o_part == nullptr || l_part == nullptr || flags == nullptr || nslots < 1) return -5;
+    const int code = q_rows_per_wg ? q_rows_per_wg : 6256;
+    if (!valid_code(code)) return -3;
+    const int rows = code % 1000;
+    const long nwork = (long)B * H * ((Nq + rows - 1) / rows);
+    if (nwork > flags_len) return -6;
+    const hipError_t e = hipMemsetAsync(flags, 0, nwork * sizeof(int), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    p.flags = flags; p.o_part = (bf16_t*)const_cast<void*>(o_part); p.l_part = const_cast<float*>(l_part);
+    p.static_min_l = fmt == FMT_F16 ? STATIC_MIN_L_PER_KEY_F16 * (float)Nk : STATIC_MIN_L_BF16;
+    iggt_launch_attn_combine(p, nslots, rows, fmt, (hipStream_t)stream);
+    IGGT_CHECK_LAUNCH();
+    p.o_part = nullptr; p.l_part = nullptr;
+    iggt_launch_flash_attn_v3(p, rows, code / 1000 - 4, fmt, false, (hipStream_t)stream);   // gated on the flags
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+// Static-bound launch: the fast kernel over every query tile, then the dynamic kernel over the tiles it flagged.  With a
+// partial workspace and a grid too small for 256-row tiles the keys are split into ranges (choose_ksplit).
 static int flash_attn_static_h16(int fmt, const void* q, const void* k, const void* v, void* o, int B, int H, int Nq,
                                  int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
-                                 long o_rs, const float* qkmax, int* flags, int flags_len, int q_rows_per_wg,
-                                 void* stream) {
+                                 long o_rs, const float* qkmax, int* flags, int flags_len, void* part_ws, long part_ws_len,
+                                 int q_rows_per_wg, void* stream) {
     AttnParams p;
     const int rc = fill_params(p, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs);
     if (rc) return rc;
     if (qkmax == nullptr || flags == nullptr || H > 16) return -5;
+    if (q_rows_per_wg == 0 && part_ws != nullptr) {
+        const int ks = choose_ksplit(B, H, Nq, Nk);
+        if (ks > 1 && part_ws_bytes(ks, B, H, Nq) <= part_ws_len) {
+            char* ws = (char*)part_ws;
+            float* l_part = (float*)(ws + (long)ks * B * Nq * H * 64 * 2);
+            int r = flash_attn_static_partial_h16(fmt, q, k, v, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, qkmax, ws,
+                                                  l_part, 0, ks, 6256, stream);
+            if (r) return r;
+            return flash_attn_static_combine_h16(fmt, ws, l_part, ks, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs,
+                                                 v_rs, o_bs, o_rs, flags, flags_len, 6256, stream);
+        }
+    }
     const int code = pick_tile(B, H, Nq, q_rows_per_wg);
     if (!valid_code(code)) return -3;
     const int rows = code % 1000;
@@ -122,29 +203,74 @@ extern "C" int iggt_flash_attn_f16_d64(const void* q, const void* k, const void*
 }
 
 extern "C" int iggt_flash_attn_static_bf16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
-                                               int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
-                                               long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
-                                               int* flags, int flags_len, int q_rows_per_wg, void* stream) {
+                                   int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
+                                   long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
+                                   int* flags, int flags_len, void* part_ws, long part_ws_bytes_len, int q_rows_per_wg,
+                                   void* stream) {
     return flash_attn_static_h16(FMT_BF16, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
-                                 qkmax, flags, flags_len, q_rows_per_wg, stream);
+                                 qkmax, flags, flags_len, part_ws, part_ws_bytes_len, q_rows_per_wg, stream);
+}
+
+extern "C" int iggt_flash_attn_static_partial_bf16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq,
+                                           int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
+                                           const float* qkmax, void* o_part, float* l_part, int slot0, int ksplit,
+                                           int q_rows_per_wg, void* stream) {
+    return flash_attn_static_partial_h16(FMT_BF16, q, k, v, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, qkmax, o_part,
+                                         l_part, slot0, ksplit, q_rows_per_wg, stream);
+}
+
+extern "C" int iggt_flash_attn_static_combine_bf16_d64(const void* o_part, const float* l_part, int nslots, const void* q,
+                                           const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
+                                           long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
+                                           long o_rs, int* flags, int flags_len, int q_rows_per_wg, void* stream) {
+    return flash_attn_static_combine_h16(FMT_BF16, o_part, l_part, nslots, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs,
+                                         v_bs, v_rs, o_bs, o_rs, flags, flags_len, q_rows_per_wg, stream);
 }
 
 extern "C" int iggt_flash_attn_static_f16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
-                                              int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
-                                              long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
-                                              int* flags, int flags_len, int q_rows_per_wg, void* stream) {
+                                   int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
+                                   long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
+                                   int* flags, int flags_len, void* part_ws, long part_ws_bytes_len, int q_rows_per_wg,
+                                   void* stream) {
     return flash_attn_static_h16(FMT_F16, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
-                                 qkmax, flags, flags_len, q_rows_per_wg, stream);
+                                 qkmax, flags, flags_len, part_ws, part_ws_bytes_len, q_rows_per_wg, stream);
+}
+
+extern "C" int iggt_flash_attn_static_partial_f16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq,
+                                           int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
+                                           const float* qkmax, void* o_part, float* l_part, int slot0, int ksplit,
+                                           int q_rows_per_wg, void* stream) {
+    return flash_attn_static_partial_h16(FMT_F16, q, k, v, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, qkmax, o_part,
+                                         l_part, slot0, ksplit, q_rows_per_wg, stream);
+}
+
+extern "C" int iggt_flash_attn_static_combine_f16_d64(const void* o_part, const float* l_part, int nslots, const void* q,
+                                           const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
+                                           long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
+                                           long o_rs, int* flags, int flags_len, int q_rows_per_wg, void* stream) {
+    return flash_attn_static_combine_h16(FMT_F16, o_part, l_part, nslots, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs,
+                                         v_bs, v_rs, o_bs, o_rs, flags, flags_len, q_rows_per_wg, stream);
 }
 
 // Name of the kernel instantiation the dispatcher launches for a shape (reports / bench.py: the roofline entry must name
 // the kernel that actually ran).  Host-only, no launch.
-extern "C" int iggt_flash_attn_d64_kernel_name(int B, int H, int Nq, int f16, int static_bound, int q_rows_per_wg,
-                                               char* buf, int buf_len) {
-    if (buf == nullptr || buf_len < 64) return -1;
-    const int code = pick_tile(B, H, Nq, q_rows_per_wg);
+extern "C" int iggt_flash_attn_d64_kernel_name(int B, int H, int Nq, int Nk, int f16, int static_bound, int with_part_ws,
+                                               int q_rows_per_wg, char* buf, int buf_len) {
+    if (buf == nullptr || buf_len < 96) return -1;
+    const int ks = (static_bound && with_part_ws && q_rows_per_wg == 0) ? choose_ksplit(B, H, Nq, Nk) : 0;
+    const int code = ks > 1 ? 6256 : pick_tile(B, H, Nq, q_rows_per_wg);
     if (!valid_code(code)) return -3;
-    snprintf(buf, buf_len, "flash_attn_d64_v3_kernel<QB=%d,KVM=%d,%s,%s>", (code % 1000) / 128, code / 1000 - 4,
-             f16 ? "f16" : "bf16", static_bound ? "static-bound" : "online-max");
+    if (ks > 1)
+        snprintf(buf, buf_len, "flash_attn_d64_v3_kernel<QB=2,KVM=2,%s,static-bound,%d key ranges> + attn_combine_kernel",
+                 f16 ? "f16" : "bf16", ks);
+    else
+        snprintf(buf, buf_len, "flash_attn_d64_v3_kernel<QB=%d,KVM=%d,%s,%s>", (code % 1000) / 128, code / 1000 - 4,
+                 f16 ? "f16" : "bf16", static_bound ? "static-bound" : "online-max");
     return 0;
+}
+
+/* bytes of partial workspace iggt_flash_attn_static_* needs to be allowed to split the keys of this shape (0: never splits) */
+extern "C" long iggt_flash_attn_static_ws_bytes(int B, int H, int Nq, int Nk) {
+    const int ks = choose_ksplit(B, H, Nq, Nk);
+    return ks > 1 ? part_ws_bytes(ks, B, H, Nq) : 0;
 }

@@ -19,6 +19,11 @@ struct AttnParams {
     const float* qkmax;
     int* flags;
     float static_min_l;
+    // key-split partial results (static bound only; ksplit == 0: one pass): workgroup (.., key range ks, ..) writes slot
+    // slot0 + ks of o_part [slots][B][Nq][H*64] (16-bit, normalised by its own row sum) and l_part [slots][B][H][Nq] (fp32)
+    int ksplit, slot0;
+    bf16_t* o_part;
+    float* l_part;
 };
 
 constexpr int KV_TILE = 64;
@@ -61,3 +66,4 @@ constexpr float STATIC_MIN_L_BF16 = 1e-30f;
 // experimental variants live in their own translation units
 int iggt_launch_flash_attn_v3(const iggt_attn::AttnParams& p, int q_rows, int kvm, int fmt, bool static_bound,
                               hipStream_t stream);
+int iggt_launch_attn_combine(const iggt_attn::AttnParams& p, int nslots, int q_rows, int fmt, hipStream_t stream);

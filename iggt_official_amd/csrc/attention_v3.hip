@@ -50,7 +50,13 @@ constexpr bool PIN_DEFAULT = false;
 constexpr bool PIN_DEFAULT = true;
 #endif
 
-template <int QB, int KVM, int FMT, bool STATIC, bool PIN = PIN_DEFAULT>
+// PART (static bound only): the workgroup covers ONE of p.ksplit equal ranges of the key macro tiles and writes a partial
+// result -- O_s / l_s as a 16-bit row and l_s in fp32 -- that attn_combine_kernel folds: with the static bound every range
+// uses the same shift, so partial sums simply add (no running-max bookkeeping between ranges).  Used (a) to balance small
+// grids: the per-rank global attention of an 8-GPU run has 352 256-row tiles for 512 workgroup slots; four key ranges make
+// 1 408 quarter-length workgroups (0.75 instead of 1.0 tile-times), and (b) to start on a rank's own keys while the K/V
+// all-gather of the other ranks is still in flight (iggt_official_amd/dist.py).
+template <int QB, int KVM, int FMT, bool STATIC, bool PIN = PIN_DEFAULT, bool PART = false>
 __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KVM * BUF_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -63,7 +69,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         if (p.flags != nullptr && p.flags[work] == 0) return;
     }
     const int qt = work % p.qtiles;
-    const int bh = work / p.qtiles;
+    int bh = work / p.qtiles, ks = 0;
+    if constexpr (PART) {   // work = ((b, h), key range, q tile): the q tiles of one key range stay adjacent (same K/V in L2)
+        ks = bh % p.ksplit;
+        bh /= p.ksplit;
+    }
     const int h = bh % p.H, b = bh / p.H;
     const bf16_t* qb_ptr = p.q + (long)b * p.q_bs + h * 64;
     const bf16_t* kb_ptr = p.k + (long)b * p.k_bs + h * 64;
@@ -262,10 +272,15 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                 pf[i][j] = __builtin_bit_cast(bf16x8, w);
             }
     };
-    const int NMT = (NT + KVM - 1) / KVM;
-    dma(0, 0);
-    __syncthreads();  // vmcnt(0) + barrier: macro tile 0 resident
-    for (int mt = 0; mt < NMT; ++mt) {
+    const int NMT_all = (NT + KVM - 1) / KVM;
+    int mt0 = 0, NMT = NMT_all;
+    if constexpr (PART) {
+        mt0 = (int)((long)ks * NMT_all / p.ksplit);
+        NMT = (int)((long)(ks + 1) * NMT_all / p.ksplit);
+    }
+    dma(mt0, mt0 & 1);
+    __syncthreads();  // vmcnt(0) + barrier: first macro tile resident
+    for (int mt = mt0; mt < NMT; ++mt) {
         if (mt + 1 < NMT) dma(mt + 1, (mt + 1) & 1);
 #pragma unroll
         for (int sub = 0; sub < KVM; ++sub) {
@@ -302,10 +317,15 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     for (int qb = 0; qb < QB; ++qb) {
         const int qr = q_base + qb * 32 + frow;
         const float l = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
-        const float inv = 1.0f / l;
-        if constexpr (STATIC) weak = weak || (qr < p.Nq && !(l >= p.static_min_l));
+        const float inv = (PART && !(l > 0.f)) ? 0.f : 1.0f / l;
+        if constexpr (STATIC && !PART) weak = weak || (qr < p.Nq && !(l >= p.static_min_l));
         if (qr < p.Nq) {
             bf16_t* dst = ob_ptr + (long)qr * p.o_rs + 4 * fhalf;
+            if constexpr (PART) {   // partial slot (slot0 + ks): dense [slot][B][Nq][H * 64] rows, l as [slot][B][H][Nq]
+                const long slot = p.slot0 + ks;
+                dst = p.o_part + ((slot * p.B + b) * p.Nq + qr) * (long)(p.H * 64) + h * 64 + 4 * fhalf;
+                if (fhalf == 0) p.l_part[((slot * p.B + b) * p.H + h) * (long)p.Nq + qr] = l;
+            }
 #pragma unroll
             for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
@@ -317,37 +337,76 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                 }
         }
     }
-    if constexpr (STATIC) {
+    if constexpr (STATIC && !PART) {
         if (weak) p.flags[work] = 1;   // benign race: every writer stores 1; the gated dynamic pass recomputes the tile
+    }
+}
+
+// out[b][row][h*64 + d] = sum_s l_s O_s / sum_s l_s over the partial slots; rows whose total row sum is below the acceptance
+// threshold flag their query tile for the gated online-max pass (same rule as the one-pass static kernel).
+template <int FMT>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const AttnParams p, int nslots, int tile_rows) {
+    const long row = blockIdx.x;                  // (b, query row)
+    const int b = (int)(row / p.Nq), qr = (int)(row - (long)b * p.Nq);
+    const int C = p.H * 64;
+    for (int c = threadIdx.x * 4; c < C; c += 256 * 4) {
+        const int h = c >> 6;
+        float L = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < nslots; ++s) {
+            const float l = p.l_part[(((long)s * p.B + b) * p.H + h) * (long)p.Nq + qr];
+            const u32x2 w = *reinterpret_cast<const u32x2*>(p.o_part + (((long)s * p.B + b) * p.Nq + qr) * (long)C + c);
+            L += l;
+            acc[0] += l * h2_lo<FMT>(w[0]); acc[1] += l * h2_hi<FMT>(w[0]);
+            acc[2] += l * h2_lo<FMT>(w[1]); acc[3] += l * h2_hi<FMT>(w[1]);
+        }
+        const float inv = 1.0f / L;
+        u32x2 o;
+        o[0] = pack_h2<FMT>(acc[0] * inv, acc[1] * inv);
+        o[1] = pack_h2<FMT>(acc[2] * inv, acc[3] * inv);
+        *reinterpret_cast<u32x2*>(p.o + (long)b * p.o_bs + (long)qr * p.o_rs + c) = o;
+        if ((c & 63) == 0 && !(L >= p.static_min_l)) p.flags[((long)b * p.H + h) * p.qtiles + qr / tile_rows] = 1;
     }
 }
 
 }  // namespace
 
 // Launched from the dispatcher in attention.hip: q_rows = 256 | 128 query rows per workgroup, kvm = 64-key tiles per macro tile.
-template <int FMT, bool STATIC>
+template <int FMT, bool STATIC, bool PART>
 static void launch_v3(const AttnParams& p_in, int q_rows, int kvm, hipStream_t stream) {
     AttnParams p = p_in;
+    const int mult = PART ? p.ksplit : 1;
     if (q_rows == 256) {
         p.qtiles = (p.Nq + 255) / 256;
-        const dim3 grid(p.B * p.H * p.qtiles), block(256);
-        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2, FMT, STATIC>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 1, FMT, STATIC>), grid, block, 0, stream, p);
+        const dim3 grid(p.B * p.H * p.qtiles * mult), block(256);
+        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2, FMT, STATIC, PIN_DEFAULT, PART>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 1, FMT, STATIC, PIN_DEFAULT, PART>), grid, block, 0, stream, p);
     } else {
         p.qtiles = (p.Nq + 127) / 128;
-        const dim3 grid(p.B * p.H * p.qtiles), block(256);
-        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 2, FMT, STATIC>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 1, FMT, STATIC>), grid, block, 0, stream, p);
+        const dim3 grid(p.B * p.H * p.qtiles * mult), block(256);
+        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 2, FMT, STATIC, PIN_DEFAULT, PART>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 1, FMT, STATIC, PIN_DEFAULT, PART>), grid, block, 0, stream, p);
     }
 }
 
 int iggt_launch_flash_attn_v3(const AttnParams& p, int q_rows, int kvm, int fmt, bool static_bound, hipStream_t stream) {
-    if (static_bound) {
-        if (fmt == FMT_F16) launch_v3<FMT_F16, true>(p, q_rows, kvm, stream);
-        else launch_v3<FMT_BF16, true>(p, q_rows, kvm, stream);
+    if (static_bound && p.ksplit > 0) {
+        if (fmt == FMT_F16) launch_v3<FMT_F16, true, true>(p, q_rows, kvm, stream);
+        else launch_v3<FMT_BF16, true, true>(p, q_rows, kvm, stream);
+    } else if (static_bound) {
+        if (fmt == FMT_F16) launch_v3<FMT_F16, true, false>(p, q_rows, kvm, stream);
+        else launch_v3<FMT_BF16, true, false>(p, q_rows, kvm, stream);
     } else {
-        if (fmt == FMT_F16) launch_v3<FMT_F16, false>(p, q_rows, kvm, stream);
-        else launch_v3<FMT_BF16, false>(p, q_rows, kvm, stream);
+        if (fmt == FMT_F16) launch_v3<FMT_F16, false, false>(p, q_rows, kvm, stream);
+        else launch_v3<FMT_BF16, false, false>(p, q_rows, kvm, stream);
     }
+    return 0;
+}
+
+int iggt_launch_attn_combine(const AttnParams& p_in, int nslots, int q_rows, int fmt, hipStream_t stream) {
+    AttnParams p = p_in;
+    p.qtiles = (p.Nq + q_rows - 1) / q_rows;
+    const dim3 grid((unsigned)((long)p.B * p.Nq)), block(256);
+    if (fmt == FMT_F16) hipLaunchKernelGGL(attn_combine_kernel<FMT_F16>, grid, block, 0, stream, p, nslots, q_rows);
+    else hipLaunchKernelGGL(attn_combine_kernel<FMT_BF16>, grid, block, 0, stream, p, nslots, q_rows);
     return 0;
 }

@@ -322,62 +322,86 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
                           (lane & 31)] = acc[i][j][r];
     }
     __syncthreads();
-#pragma unroll 4
-    for (int idx = tid; idx < EPI_ROWS * C4; idx += THREADS) {
-        const int row = idx / C4, c4 = idx - row * C4;
-        const long m = m0 + pass * EPI_ROWS + row;
-        const int n = n0 + c4 * 4;
-        if (m >= p.M || n >= p.Cout) continue;
-        const int img = (int)(m / hw);
-        const int rem = (int)(m - (long)img * hw);
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        int co = n, py = 0, px = 0;
-        if (p.ps > 1) {
-            const int phase = n / p.cout_phys;
-            co = n - phase * p.cout_phys;
-            py = phase / p.ps;
-            px = phase - py * p.ps;
-        }
-        const long pix = ((long)img * p.Hout + oy * p.osy + p.ooy + py) * p.Wout + ox * p.osx + p.oox + px;
-        f32x4 v = *reinterpret_cast<const f32x4*>(stile + row * BN + c4 * 4);
-        const bool full = (n + 3 < p.Cout);  // Cout % 4 != 0 only for the padded 42-channel bottleneck
-        if (p.bias) {
+    // Batches of EB output segments per thread: addresses and the residual loads of the whole batch first, stores after --
+    // with load / add / store per segment every residual load waits behind the previous (possibly aliasing) store and the
+    // epilogue of the residual layers ran with one access in flight (same finding as gemm_bf16_t256.hip).
+    constexpr int EB = NPASS > 1 ? 2 : 4;   // accumulators of the later passes are still live in the two-pass (256-row) tile
+#pragma unroll 1
+    for (int idx0 = tid; idx0 < EPI_ROWS * C4; idx0 += EB * THREADS) {
+        long pixs[EB];
+        int ns[EB], cos[EB];
+        bool ok[EB];
+        f32x4 r1[EB], r2[EB];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (full || n + e < p.Cout) ? p.bias[n + e] : 0.f;
-        }
-        if (p.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (p.act == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
-        } else if (p.act == 3) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
-        }
-        if (full) {
-            if (p.res) {
-                f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + co);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += p.relu_res ? fmaxf(rv[e], 0.f) : rv[e];
-                if (p.res2) {
-                    rv = *reinterpret_cast<const f32x4*>(p.res2 + pix * p.ldr + co);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
-                }
+        for (int u = 0; u < EB; ++u) {
+            const int idx = idx0 + u * THREADS;
+            const int row = idx / C4, c4 = idx - row * C4;
+            const long m = m0 + pass * EPI_ROWS + row;
+            const int n = n0 + c4 * 4;
+            ok[u] = idx < EPI_ROWS * C4 && m < p.M && n < p.Cout;
+            const long mm = ok[u] ? m : m0;
+            const int img = (int)(mm / hw);
+            const int rem = (int)(mm - (long)img * hw);
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            int co = n, py = 0, px = 0;
+            if (p.ps > 1) {
+                const int phase = n / p.cout_phys;
+                co = n - phase * p.cout_phys;
+                py = phase / p.ps;
+                px = phase - py * p.ps;
             }
-            *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + co) = v;
-        } else {
+            pixs[u] = ((long)img * p.Hout + oy * p.osy + p.ooy + py) * p.Wout + ox * p.osx + p.oox + px;
+            ns[u] = n;
+            cos[u] = co;
+            const bool full = ok[u] && (n + 3 < p.Cout);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (n + e >= p.Cout) break;
-                float val = v[e];
+            for (int e = 0; e < 4; ++e) { r1[u][e] = 0.f; r2[u][e] = 0.f; }
+            if (full && p.res) {
+                r1[u] = *reinterpret_cast<const f32x4*>(p.res + pixs[u] * p.ldr + co);
+                if (p.res2) r2[u] = *reinterpret_cast<const f32x4*>(p.res2 + pixs[u] * p.ldr + co);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+            if (!ok[u]) continue;
+            const int idx = idx0 + u * THREADS;
+            const int row = idx / C4, c4 = idx - row * C4;
+            const int n = ns[u], co = cos[u];
+            const long pix = pixs[u];
+            f32x4 v = *reinterpret_cast<const f32x4*>(stile + row * BN + c4 * 4);
+            const bool full = (n + 3 < p.Cout);  // Cout % 4 != 0 only for the padded 42-channel bottleneck
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (full || n + e < p.Cout) ? p.bias[n + e] : 0.f;
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+            } else if (p.act == 3) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+            }
+            if (full) {
                 if (p.res) {
-                    const float rv = p.res[pix * p.ldr + co + e];
-                    val += p.relu_res ? fmaxf(rv, 0.f) : rv;
-                    if (p.res2) val += p.res2[pix * p.ldr + co + e];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (p.relu_res ? fmaxf(r1[u][e], 0.f) : r1[u][e]) + r2[u][e];
                 }
-                p.y[pix * p.ldy + co + e] = val;
+                *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + co) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= p.Cout) break;
+                    float val = v[e];
+                    if (p.res) {
+                        const float rv = p.res[pix * p.ldr + co + e];
+                        val += p.relu_res ? fmaxf(rv, 0.f) : rv;
+                        if (p.res2) val += p.res2[pix * p.ldr + co + e];
+                    }
+                    p.y[pix * p.ldy + co + e] = val;
+                }
             }
         }
     }

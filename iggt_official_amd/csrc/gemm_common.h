@@ -46,6 +46,23 @@ IGGT_DEVINL void gemm_epilogue_tile(const GemmParams& p, const f32x16& acc, int 
     if (n >= p.N) return;
     const float bias = p.bias ? p.bias[n] : 0.f;
     const float gamma = (MODE == 0 || MODE == 2) ? (p.gamma ? p.gamma[n] : 1.f) : 1.f;
+    if (MODE == 0 && p.out_f32 && p.accumulate && p.rows_in == 0 && p.act == 0) {
+        // residual accumulate: request the 16 old values before the first store -- as load / add / store per element every
+        // load has to wait behind the previous (possibly aliasing) store and the epilogue runs at one access in flight
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int m = m_base + mfma32_row(r, lane);
+            m = m < p.M ? m : p.M - 1;
+            old[r] = p.out_f32[(long)m * p.ldo + n];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_base + mfma32_row(r, lane);
+            if (m < p.M) p.out_f32[(long)m * p.ldo + n] = fmaf(acc[r] + bias, gamma, old[r]);
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m_base + mfma32_row(r, lane);

@@ -245,9 +245,11 @@ class Block(nn.Module):
             with profiling.region("global_attn" if batch == 1 else "frame_attn", (batch, tokens, Nk)):
                 if static:
                     flags = ws.get("attn_flags", (batch * H * ((tokens + 127) // 128),), torch.int32, dev)
+                    nws = _C.static_attn_ws_bytes(batch, H, tokens, Nk) if q_rows_per_wg == 0 else 0
+                    part_ws = ws.get("attn_part", (nws,), torch.uint8, dev) if nws else None
                     _C.flash_attn_d64_static(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
                                              tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,
-                                             qkmax, flags, q_rows_per_wg)
+                                             qkmax, flags, q_rows_per_wg, part_ws)
                 else:
                     _C.flash_attn_d64(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
                                       tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,

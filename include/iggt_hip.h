@@ -63,20 +63,49 @@ int iggt_flash_attn_f16_d64(const void* q, const void* k, const void* v, void* o
  * 2^(s - bound) from the first tile on: no running maximum, no rescale.  Rows whose numerators would sink into the
  * 16-bit subnormal range (row sum below a fixed threshold) get their query tile flagged in `flags` (int[flags_len],
  * scratch, >= B * H * ceil(Nq / 128) entries, zeroed here) and are recomputed by the online-max kernel in the same call, so
- * the result meets the tolerance of iggt_flash_attn_* for ANY input.  Same reference operation as above. */
+ * the result meets the tolerance of iggt_flash_attn_* for ANY input.  part_ws (NULL or part_ws_len >=
+ * iggt_flash_attn_static_ws_bytes(..) bytes of scratch) lets a grid too small for the chip split the keys into ranges whose
+ * partial results are folded by a second kernel (they simply add under a common static bound).  Same reference operation. */
 int iggt_flash_attn_static_bf16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
                                     int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
                                     long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
-                                    int* flags, int flags_len, int q_rows_per_wg, void* stream);
+                                    int* flags, int flags_len, void* part_ws, long part_ws_len, int q_rows_per_wg,
+                                    void* stream);
 int iggt_flash_attn_static_f16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
                                    int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
                                    long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
-                                   int* flags, int flags_len, int q_rows_per_wg, void* stream);
+                                   int* flags, int flags_len, void* part_ws, long part_ws_len, int q_rows_per_wg,
+                                   void* stream);
+long iggt_flash_attn_static_ws_bytes(int B, int H, int Nq, int Nk);
+
+/* The two halves of the split form, for callers that own the key segments themselves (multi-GPU: a rank's own keys while the
+ * all-gather of the others is in flight, iggt_official_amd/dist.py):
+ *   _partial_: static-bound pass of ALL queries over ONE key segment (k, v, Nk), cut into `ksplit` ranges -> slots
+ *              [slot0, slot0 + ksplit) of o_part [slots][B][Nq][H*64] (16-bit, each row normalised by its own row sum) and
+ *              l_part [slots][B][H][Nq] (fp32 row sums).  Every segment must use the SAME qkmax.
+ *   _combine_: o = sum_s l_s O_s / sum_s l_s over nslots slots, then the flag / online-max fallback pass over the full key
+ *              set (k, v, Nk).  q_rows_per_wg: 0 (= 6256) or the code both calls were given. */
+int iggt_flash_attn_static_partial_bf16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq, int Nk,
+                                            long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
+                                            const float* qkmax, void* o_part, float* l_part, int slot0, int ksplit,
+                                            int q_rows_per_wg, void* stream);
+int iggt_flash_attn_static_partial_f16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq, int Nk,
+                                           long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
+                                           const float* qkmax, void* o_part, float* l_part, int slot0, int ksplit,
+                                           int q_rows_per_wg, void* stream);
+int iggt_flash_attn_static_combine_bf16_d64(const void* o_part, const float* l_part, int nslots, const void* q,
+                                            const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
+                                            long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
+                                            long o_rs, int* flags, int flags_len, int q_rows_per_wg, void* stream);
+int iggt_flash_attn_static_combine_f16_d64(const void* o_part, const float* l_part, int nslots, const void* q,
+                                           const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
+                                           long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
+                                           long o_rs, int* flags, int flags_len, int q_rows_per_wg, void* stream);
 
 /* Writes the name of the kernel instantiation the attention dispatcher picks for a shape into buf (host only, no launch;
- * buf_len >= 64): reports must name the kernel that actually ran. */
-int iggt_flash_attn_d64_kernel_name(int B, int H, int Nq, int f16, int static_bound, int q_rows_per_wg,
-                                    char* buf, int buf_len);
+ * buf_len >= 96): reports must name the kernel that actually ran. */
+int iggt_flash_attn_d64_kernel_name(int B, int H, int Nq, int Nk, int f16, int static_bound, int with_part_ws,
+                                    int q_rows_per_wg, char* buf, int buf_len);
 
 /* LayerNorm over C in {128 (no concat / remap), 256, 512, 1024, 2048}; fp32 in ((x0|x1) concatenation when x1 != NULL); out_type 0 = bf16,
  * 1 = fp32, 2 = fp16; optional input-row remap in_row = (r / rows_in) * rows_stride + row_off + r % rows_in and

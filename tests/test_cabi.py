@@ -19,7 +19,7 @@ def lib():
 def _declared():
     src = open(os.path.join(ROOT, "include", "iggt_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(iggt_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|long)\s+(iggt_\w+)\s*\(", src)))
 
 
 def test_header_symbols_exported(lib):
@@ -36,7 +36,7 @@ def test_binding_matches_header():
     src = open(os.path.join(ROOT, "include", "iggt_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     for name, argtypes in _C._SIGNATURES.items():
-        m = re.search(r"\bint\s+" + name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
+        m = re.search(r"\b(?:int|long)\s+" + name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
         assert m, name
         params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
         assert len(params) == len(argtypes), (name, len(params), len(argtypes))

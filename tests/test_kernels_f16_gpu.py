@@ -166,14 +166,21 @@ def _static_attn(C, qkv, B, H, Nq, Nk, N, tile, dtype):
 
 
 @pytest.mark.parametrize("dtype", [F16, torch.bfloat16])
+@pytest.mark.parametrize("normed", [True, False])
 @pytest.mark.parametrize("B,H,Nq,Nk,tile", [(2, 16, 1374, 1374, 0), (1, 16, 4122, 4122, 0), (3, 4, 21, 21, 0),
                                             (1, 16, 4122, 4122, 5256), (1, 16, 2748, 5496, 6256),
                                             (2, 3, 1374, 1374, 6128), (1, 2, 300, 777, 6256), (1, 2, 300, 777, 5128),
                                             (1, 1, 40, 64, 6256), (1, 2, 1000, 65, 6256), (1, 2, 500, 129, 6128)])
-def test_flash_attn_static_bound(C, dtype, B, H, Nq, Nk, tile):
+def test_flash_attn_static_bound(C, dtype, normed, B, H, Nq, Nk, tile):
+    """normed: q and k head vectors of equal norm, as the model's per-head LayerNorm makes them (|.| = 8): the bound is
+    tight and no tile may need the fallback.  Not normed: Gaussian vectors whose largest norms sit ~35 % above the typical
+    one -- the bound loosens by several bits, some tiles take the fallback pass; the result must be right either way."""
     Cdim = H * 64
     N = max(Nq, Nk)
     qkv = _rand((B * N, 3 * Cdim), 120 + Nq, 1.0, dtype)
+    if normed:
+        qk = qkv[:, :2 * Cdim].float().view(B * N, 2 * H, 64)
+        qkv[:, :2 * Cdim] = (qk / qk.norm(dim=-1, keepdim=True) * 8.0).view(B * N, 2 * Cdim).to(dtype)
     qkv[:, :Cdim] *= 0.125 * 1.4426950408889634 * 1.3      # "pre-scaled" q: scores ~ N(0, (1.9 bit)^2)
     o, ref, flags = _static_attn(C, qkv, B, H, Nq, Nk, N, tile, dtype)
     assert not torch.isnan(o.float()).any()
@@ -185,8 +192,8 @@ def test_flash_attn_static_bound(C, dtype, B, H, Nq, Nk, tile):
     else:
         assert mx < 1.5e-2 and l2 < 4e-3, (mx, l2)
     assert torch.all(flags[-3:] == 7)                      # scratch beyond the work list untouched
-    if tile:
-        assert int(flags[:-3].sum()) == 0                  # nothing needed the fallback on this benign input
+    if tile and normed:
+        assert int(flags[:-3].sum()) == 0                  # LayerNorm-like operands: nothing needs the fallback
 
 
 def test_flash_attn_static_bound_fallback_rows(C):
@@ -211,6 +218,74 @@ def test_flash_attn_static_bound_fallback_rows(C):
     for r in (0, 3, 124, 125, 3999):
         e = _relerr(o[r], ref[r])
         assert e[1] < 1e-3, (r, e)
+
+
+@pytest.mark.parametrize("dtype", [F16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 300, 4000), (1, 16, 1374, 5496), (2, 3, 500, 2100)])
+def test_flash_attn_static_key_split(C, dtype, B, H, Nq, Nk):
+    """Small grids: with a partial workspace the dispatcher splits the keys into ranges (partial results add under the common
+    static bound) -- the same answer as one pass; and the two-segment form the multi-GPU path uses (own keys first, the
+    other ranks' keys later, explicit slots) gives it too."""
+    Cdim = H * 64
+    N = max(Nq, Nk)
+    qkv = _rand((B * N, 3 * Cdim), 170 + Nq, 1.0, dtype)
+    qk = qkv[:, :2 * Cdim].float().view(B * N, 2 * H, 64)
+    qkv[:, :2 * Cdim] = (qk / qk.norm(dim=-1, keepdim=True) * 8.0).view(B * N, 2 * Cdim).to(dtype)
+    qkv[:, :Cdim] *= 0.125 * 1.4426950408889634 * 1.3
+    x = qkv.view(B, N, 3, H, 64)
+    qkmax = torch.zeros(32, device="cuda")
+    qkmax[:H] = x[:, :Nq, 0].float().norm(dim=-1).amax(dim=(0, 1))
+    qkmax[16:16 + H] = x[:, :Nk, 1].float().norm(dim=-1).amax(dim=(0, 1))
+    strides = (N * 3 * Cdim, 3 * Cdim, N * 3 * Cdim, 3 * Cdim, N * 3 * Cdim, 3 * Cdim)
+    q, k, v = x[:, :Nq, 0].transpose(1, 2), x[:, :Nk, 1].transpose(1, 2), x[:, :Nk, 2].transpose(1, 2)
+    ref = _attn_ref(q, k, v, 0.6931471805599453).transpose(1, 2).reshape(B * Nq, Cdim)
+    tol = (2e-3, 5e-4) if dtype == F16 else (1.5e-2, 4e-3)
+    flags = torch.zeros(B * H * ((Nq + 127) // 128), dtype=torch.int32, device="cuda")
+    # (a) automatic split
+    nws = C.static_attn_ws_bytes(B, H, Nq, Nk)
+    assert nws > 0
+    ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+    o = torch.full((B * Nq, Cdim), float("nan"), dtype=dtype, device="cuda")
+    C.flash_attn_d64_static(qkv, qkv[:, Cdim:], qkv[:, 2 * Cdim:], o, B, H, Nq, Nk, *strides, Nq * Cdim, Cdim, qkmax, flags,
+                            0, ws)
+    mx, l2 = _relerr(o, ref)
+    assert not torch.isnan(o.float()).any() and mx < tol[0] and l2 < tol[1], (mx, l2)
+    assert int(flags.sum()) == 0
+    # (b) explicit segments: keys [0, n1) in one range, keys [n1, Nk) in three
+    n1 = (Nk // 3 // 8) * 8
+    o_part = torch.full((4, B, Nq, Cdim), float("nan"), dtype=dtype, device="cuda")
+    l_part = torch.full((4, B, H, Nq), float("nan"), device="cuda")
+    kk, vv = qkv[:, Cdim:], qkv[:, 2 * Cdim:]
+    C.flash_attn_d64_static_partial(qkv, kk, vv, B, H, Nq, n1, *strides, qkmax, o_part, l_part, 0, 1)
+    C.flash_attn_d64_static_partial(qkv, kk[n1:], vv[n1:], B, H, Nq, Nk - n1, *strides, qkmax, o_part, l_part, 1, 3)
+    o2 = torch.full((B * Nq, Cdim), float("nan"), dtype=dtype, device="cuda")
+    C.flash_attn_d64_static_combine(o_part, l_part, 4, qkv, kk, vv, o2, B, H, Nq, Nk, *strides, Nq * Cdim, Cdim, flags)
+    mx, l2 = _relerr(o2, ref)
+    report(f"attn_static_split_{'f16' if dtype == F16 else 'bf16'}_B{B}_H{H}_{Nq}x{Nk}", dict(max=mx, l2=l2))
+    assert not torch.isnan(o2.float()).any() and mx < tol[0] and l2 < tol[1], (mx, l2)
+
+
+def test_flash_attn_static_key_split_fallback(C):
+    """Rows below the acceptance threshold are flagged by the combine kernel and redone over all keys."""
+    H, Nq, Nk = 2, 500, 4000
+    Cdim = H * 64
+    qkv = _rand((Nk, 3 * Cdim), 181, 1.0, F16)
+    x = qkv.view(Nk, 3, H, 64)
+    x[:, 0] *= 0.125 * 1.4426950408889634 * 3.0
+    x[::3, 0] *= 0.01
+    qkmax = torch.zeros(32, device="cuda")
+    qkmax[:H] = x[:Nq, 0].float().norm(dim=-1).amax(0)
+    qkmax[16:16 + H] = x[:, 1].float().norm(dim=-1).amax(0)
+    flags = torch.zeros(H * 4, dtype=torch.int32, device="cuda")
+    ws = torch.empty(C.static_attn_ws_bytes(1, H, Nq, Nk), dtype=torch.uint8, device="cuda")
+    assert ws.numel() > 0
+    o = torch.full((Nq, Cdim), float("nan"), dtype=F16, device="cuda")
+    C.flash_attn_d64_static(qkv, qkv[:, Cdim:], qkv[:, 2 * Cdim:], o, 1, H, Nq, Nk, 0, 3 * Cdim, 0, 3 * Cdim, 0, 3 * Cdim,
+                            0, Cdim, qkmax, flags, 0, ws)
+    q, k, v = x[:Nq, 0].transpose(0, 1), x[:, 1].transpose(0, 1), x[:, 2].transpose(0, 1)
+    ref = _attn_ref(q, k, v, 0.6931471805599453).transpose(0, 1).reshape(Nq, Cdim)
+    mx, l2 = _relerr(o, ref)
+    assert int(flags.sum()) > 0 and not torch.isnan(o.float()).any() and mx < 2e-3 and l2 < 5e-4, (int(flags.sum()), mx, l2)
 
 
 def test_qknorm_rope_prescale_and_norm_maxima(C):
