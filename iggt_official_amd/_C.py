@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -91,6 +91,7 @@ _SIGNATURES = {
                                _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p],
     "iggt_u8hwc_to_f32chw": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                              _c_int, _c_float, _c_void_p],
+    "iggt_count_saturated_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "iggt_write_special_tokens": [_c_void_p, _c_long, _c_long, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_void_p],
 }
@@ -568,3 +569,12 @@ def u8hwc_to_f32chw(src, dst, crop_y, crop_x, pad_y, pad_x, h, w, pad_value=1.0)
                                      crop_y, crop_x, pad_y, pad_x, h, w, float(pad_value), _stream())
     _check(rc, "iggt_u8hwc_to_f32chw")
     return dst
+
+
+def count_saturated(x, counter):
+    """counter (int64 [1], device) += number of saturated (fp16: |x| = 65504) or non-finite entries of the 16-bit matrix x."""
+    _dev(x, counter)
+    assert x.dtype in H16 and x.dim() == 2 and x.stride(1) == 1 and counter.dtype == torch.int64
+    rc = load().iggt_count_saturated_h16(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], int(x.dtype == torch.float16),
+                                         counter.data_ptr(), _stream())
+    _check(rc, "iggt_count_saturated_h16")

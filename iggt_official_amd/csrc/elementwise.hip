@@ -230,22 +230,21 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
         *reinterpret_cast<u32x4*>(p.v_out + vg * p.vgs + (long)t * p.ldv + (vh - vg * p.hg) * 64 + (tid & 7) * 8) = vv;
     }
     }   // token loop
-    if (p.qkmax != nullptr && j == 0) p.qkmax[32 + 32 * (long)blockIdx.x + which * 16 + head] = sqrtf(nmax2);
+    if (p.qkmax != nullptr && j == 0) p.qkmax[32 + (long)(which * 16 + head) * QK_MAX_BLOCKS + blockIdx.x] = sqrtf(nmax2);
 }
 
-// qkmax[s] = max over blocks of the per-block maxima written by qknorm_rope_kernel (s = q|k * 16 + head).
-__global__ __launch_bounds__(1024) void qkmax_reduce_kernel(float* qkmax, int nblocks) {
-    __shared__ float sm[32][33];
-    const int s = threadIdx.x & 31, g = threadIdx.x >> 5;   // 32 slots x 32 row groups
+// qkmax[s] = max over blocks of the per-block maxima written by qknorm_rope_kernel (s = q|k * 16 + head); one workgroup
+// per slot, the slot's partial maxima are contiguous.
+__global__ __launch_bounds__(256) void qkmax_reduce_kernel(float* qkmax, int nblocks) {
+    __shared__ float sm[4];
+    const int s = blockIdx.x;
     float m = 0.f;
-    for (int b = g; b < nblocks; b += 32) m = fmaxf(m, qkmax[32 + 32 * (long)b + s]);
-    sm[g][s] = m;
-    __syncthreads();
-    if (g == 0) {
+    for (int b = threadIdx.x; b < nblocks; b += 256) m = fmaxf(m, qkmax[32 + (long)s * QK_MAX_BLOCKS + b]);
 #pragma unroll
-        for (int i = 1; i < 32; ++i) m = fmaxf(m, sm[i][s]);
-        qkmax[s] = m;
-    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) qkmax[s] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -602,7 +601,7 @@ static int qknorm_rope_h16(int fmt, const void* qkv, long ld_in, void* q_out, lo
     else hipLaunchKernelGGL(qknorm_rope_kernel<FMT_BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
     if (qkmax != nullptr) {
-        hipLaunchKernelGGL(qkmax_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, qkmax, grid);
+        hipLaunchKernelGGL(qkmax_reduce_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, qkmax, grid);
         IGGT_CHECK_LAUNCH();
     }
     return 0;
@@ -651,6 +650,32 @@ extern "C" int iggt_write_special_tokens(float* dst, long view_stride, long ldd,
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(write_special_tokens_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+// Debug telemetry for the fp16 operand format: counts the entries of a 16-bit matrix that sit at the saturation value
+// (|x| = 65504: a clamped store, common.h pack_h2) or are not finite.  Run by the host model after every 16-bit-producing
+// kernel when IGGT_DEBUG_SATURATION=1 (iggt_official_amd/precision.py); no cost otherwise.
+__global__ __launch_bounds__(256) void count_saturated_kernel(const uint16_t* x, long ld, int rows, int cols, int f16,
+                                                              unsigned long long* counter) {
+    unsigned int local = 0;
+    const long total = (long)rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / cols;
+        const uint16_t v = x[r * ld + (i - r * cols)] & 0x7fffu;
+        local += f16 ? (v >= 0x7bffu) : (v >= 0x7f80u);   // fp16: max finite 0x7bff; bf16: inf / nan only (no clamp needed)
+    }
+    local = (unsigned int)wave_sum((float)local);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(counter, (unsigned long long)local);
+}
+
+extern "C" int iggt_count_saturated_h16(const void* x, long ld, int rows, int cols, int f16, void* counter, void* stream) {
+    if (rows <= 0 || cols <= 0 || counter == nullptr) return -1;
+    const long total = (long)rows * cols;
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(count_saturated_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ld, rows, cols,
+                       f16, (unsigned long long*)counter);
     IGGT_CHECK_LAUNCH();
     return 0;
 }

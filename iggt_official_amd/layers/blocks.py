@@ -151,6 +151,8 @@ class Block(nn.Module):
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (dt, precision.mean_compensation())
         if self._packed_key != key:
             dev = ps[0].device
+            for nm, w_ in zip(("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"), ps):
+                precision.check_operand_range(nm + ".weight", w_, dt)
             f32 = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
             ones = lambda: torch.ones(self.dim, device=dev)  # noqa: E731
             self._packed = dict(
@@ -204,8 +206,12 @@ class Block(nn.Module):
         ao = ws.get("ao", (T, C), dt, dev)
         hid = ws.get("hid", (T, pk["w_fc1"].shape[0]), dt, dev)
 
+        sat = precision.debug_saturation()
         _C.layernorm(x2d, pk["n1w"], pk["n1b"], xn, self.norm1.eps)
         _C.gemm_h16(xn, pk["w_qkv"], qkv, bias=compensated_bias(ws, xn, pk["dw_qkv"], pk["b_qkv"]))
+        if sat:
+            precision.count_saturation("norm1", xn)
+            precision.count_saturation("qkv", qkv)
         k_src, v_src, kv_rs, Nk, k_bs = qkv[:, C:], qkv[:, 2 * C:], 3 * C, tokens, tokens * 3 * C
         grouped = None
         # static-bound softmax (csrc/attention_v3.hip): q leaves the q/k-norm kernel pre-scaled by scale * log2 e together
@@ -273,10 +279,15 @@ class Block(nn.Module):
                         kv_gather.event(g).record(st)
                 for g in range(G):
                     main.wait_event(kv_gather.event(g))
+        if sat:
+            precision.count_saturation("attn_out", ao)
         _C.gemm_h16(ao, pk["w_proj"], x2d, bias=compensated_bias(ws, ao, pk["dw_proj"], pk["b_proj"]), gamma=pk["g1"],
                     accumulate=True)
         _C.layernorm(x2d, pk["n2w"], pk["n2b"], xn, self.norm2.eps)
         _C.gemm_h16(xn, pk["w_fc1"], hid, bias=compensated_bias(ws, xn, pk["dw_fc1"], pk["b_fc1"]), act=1)
+        if sat:
+            precision.count_saturation("norm2", xn)
+            precision.count_saturation("mlp_hidden", hid)
         _C.gemm_h16(hid, pk["w_fc2"], x2d, bias=compensated_bias(ws, hid, pk["dw_fc2"], pk["b_fc2"]), gamma=pk["g2"],
                     accumulate=True)
         return x2d

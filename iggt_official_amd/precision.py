@@ -74,3 +74,50 @@ def static_softmax() -> bool:
 def set_static_softmax(on: bool) -> None:
     global _static_softmax
     _static_softmax = bool(on)
+
+
+# fp16 range telemetry (debug): IGGT_DEBUG_SATURATION=1 makes the block engine count, after every kernel that stores 16-bit
+# activations (LayerNorm output, qkv, attention output, MLP hidden), the entries that were clamped to +-65504 or are not
+# finite (csrc/elementwise.hip count_saturated_kernel).  fp16 stores never produce inf -- they clamp -- so a silent
+# saturation is exactly what this counter exposes; a non-zero count means: run that checkpoint with bf16 operands.
+_debug_sat = os.environ.get("IGGT_DEBUG_SATURATION", "0") == "1"
+_sat_counters = {}
+
+
+def debug_saturation() -> bool:
+    return _debug_sat
+
+
+def set_debug_saturation(on: bool) -> None:
+    global _debug_sat
+    _debug_sat = bool(on)
+    _sat_counters.clear()
+
+
+def count_saturation(site: str, x) -> None:
+    """(block engine hook) accumulate the saturated-entry count of the 16-bit matrix x under `site`."""
+    from . import _C
+
+    c = _sat_counters.get((site, str(x.device)))
+    if c is None:
+        c = _sat_counters[(site, str(x.device))] = torch.zeros(1, dtype=torch.int64, device=x.device)
+    _C.count_saturated(x, c)
+
+
+def saturation_report() -> dict:
+    """{site: clamped / non-finite 16-bit stores since set_debug_saturation(True)} (synchronises)."""
+    out = {}
+    for (site, _dev), c in _sat_counters.items():
+        out[site] = out.get(site, 0) + int(c.item())
+    return out
+
+
+def check_operand_range(name: str, w: torch.Tensor, dt: torch.dtype) -> None:
+    """Weights are converted with a plain cast (no clamp): a value beyond the fp16 range would become inf and poison every
+    output.  Called once per pack (blocks.py); the comparison runs on the device, the verdict is read back once."""
+    if dt != torch.float16:
+        return
+    m = float(w.detach().abs().max())
+    if not (m <= 65504.0):
+        raise ValueError(f"{name}: max |w| = {m:.4g} does not fit fp16 operands; select bf16 operands "
+                         "(IGGT_OPERAND_DTYPE=bf16 or precision.set_operand_dtype(torch.bfloat16))")

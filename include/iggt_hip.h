@@ -176,6 +176,11 @@ int iggt_colmean_h16(const void* x, long ld, int rows, int K, int row_step, int 
 int iggt_bias_correct_h16(const void* dw, long ldw, int N, int K, const float* mu, const float* bias, float* out,
                           int f16, void* stream);
 
+/* Debug telemetry of the fp16 operand format: adds to *counter (device unsigned long long) the number of entries of the 16-bit
+ * matrix x [rows][cols] (row stride ld) that are saturated (|x| = 65504, i.e. a clamped store) or not finite (f16 = 1), or
+ * not finite (f16 = 0, bf16).  No counterpart in the reference (its GPU mode is bf16 autocast, demo.py:193-195). */
+int iggt_count_saturated_h16(const void* x, long ld, int rows, int cols, int f16, void* counter, void* stream);
+
 /* dst[s][row_off + r][:] = (s == 0 && first_view_is_zero ? src0 : src1)[r][:]  (fp32).
  * Replaces iggt/layers/vision_transformer.py:222-234 and iggt/models/aggregator.py:230-234,338-361. */
 int iggt_write_special_tokens(float* dst, long view_stride, long ldd, const float* src0,

@@ -35,7 +35,7 @@ def t(fn, n=7):
     return sorted(ts)[len(ts) // 2]
 
 
-for nrank in (8, 4, 2):
+for nrank in (8, 4, 2, 1):
     Nq = T // nrank
     fl = 4.0 * Nq * T * C
     one = t(lambda: _C.flash_attn_d64_static(qkv, qkv[:, C:], qkv[:, 2 * C:], o, 1, H, Nq, T, 0, 3 * C, 0, 3 * C, 0, 3 * C, 0, C,

@@ -36,3 +36,13 @@ for S in [int(x) for x in (sys.argv[1:] or ["32", "4"])]:
             fn = lambda: _C.gemm_h16(a, w, out, bias=b, **kw)  # noqa: E731
         ms = t(fn)
         print(f"S={S} gemm {name:5s} M={T} N={N} K={K}: {ms:8.3f} ms  {2 * T * N * K / ms / 1e9:7.1f} TF/s", flush=True)
+
+# cross-check (NOT part of the product): what the vendor library reaches on the same shapes (fp16 in / fp16 out, no epilogue)
+if os.environ.get("IGGT_GEMM_XCHECK", "0") == "1":
+    for S in (32, 4):
+        T = S * P
+        for name, N, K in [("qkv", 3 * C, C), ("proj", C, C), ("fc1", 4 * C, C), ("fc2", C, 4 * C)]:
+            a = torch.randn(T, K, device="cuda").half()
+            w = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
+            ms = t(lambda: torch.mm(a, w.t()))
+            print(f"S={S} hipBLASLt {name:5s} M={T} N={N} K={K}: {ms:8.3f} ms  {2 * T * N * K / ms / 1e9:7.1f} TF/s", flush=True)

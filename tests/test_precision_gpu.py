@@ -1,0 +1,106 @@
+"""fp16 operand-format safety nets (GPU): the debug saturation counter, outlier channels of the kind real DINOv2 / VGGT
+checkpoints carry ("massive activations"), weight-range validation at pack time and pack invalidation on load_state_dict."""
+import pytest
+import torch
+
+from helpers import build_gpu_model, errors, schema
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _reset():
+    from iggt_official_amd import precision
+
+    yield
+    precision.set_debug_saturation(False)
+
+
+def _tiny_inputs():
+    from oracle import weights
+
+    return weights.make_images(2, 56, 56, seed=1, device="cuda")
+
+
+def test_saturation_counter_and_outlier_channels():
+    """(a) stress weights: nothing saturates.  (b) four residual-stream channels 200x larger than the rest (camera / register
+    tokens and a LayerScale row): still nothing saturates and the outputs stay within 1e-3 of the CPU fp32 restatement of the
+    reference.  (c) an MLP weight row scaled until the hidden activation leaves the fp16 range: the counter reports it."""
+    from iggt_official_amd import precision
+    from oracle import restate, weights
+
+    model = build_gpu_model("stress", 0)
+    images = _tiny_inputs()
+    precision.set_debug_saturation(True)
+    model(images)
+    rep = precision.saturation_report()
+    assert rep and all(v == 0 for v in rep.values()), rep
+
+    sd = weights.fill_state_dict(schema(), seed=0, mode="stress", device="cuda")
+    sd["aggregator.register_token"][..., :4] *= 200.0
+    sd["aggregator.camera_token"][..., 7:9] *= 200.0
+    sd["aggregator.frame_blocks.2.ls2.gamma"][100:104] *= 30.0
+    try:
+        model.load_state_dict(sd, strict=False)
+        precision.set_debug_saturation(True)
+        pred = model(images)
+        torch.cuda.synchronize()
+        rep = precision.saturation_report()
+        assert all(v == 0 for v in rep.values()), rep
+        cpu_sd = {k: v.cpu() for k, v in sd.items()}
+        with torch.no_grad():
+            ref = restate.iggt_forward(cpu_sd, images.cpu(), with_part=True)
+        for k in ("depth", "world_points", "part_feat"):
+            e = errors(pred[k], ref[k])
+            assert e[1] < 1e-3, (k, e)
+
+        sd["aggregator.global_blocks.1.mlp.fc1.weight"][:8] *= 3.0e4      # hidden activations of 8 units ~ 1e5 > 65504
+        model.load_state_dict(sd, strict=False)
+        precision.set_debug_saturation(True)
+        model(images)
+        rep = precision.saturation_report()
+        assert rep["mlp_hidden"] > 0, rep
+    finally:
+        model.load_state_dict(weights.fill_state_dict(schema(), seed=0, mode="stress", device="cuda"), strict=False)
+
+
+def test_weight_beyond_fp16_range_is_rejected_at_pack_time():
+    from iggt_official_amd import precision
+    from oracle import weights
+
+    model = build_gpu_model("stress", 0)
+    sd = weights.fill_state_dict(schema(), seed=0, mode="stress", device="cuda")
+    good = sd["aggregator.frame_blocks.0.attn.proj.weight"].clone()
+    sd["aggregator.frame_blocks.0.attn.proj.weight"][3, 5] = 1.0e5
+    try:
+        model.load_state_dict(sd, strict=False)
+        with pytest.raises(ValueError, match="fp16"):
+            model(_tiny_inputs())
+        old = precision.operand_dtype()
+        try:
+            precision.set_operand_dtype(torch.bfloat16)        # the documented way out: bf16 operands have fp32's range
+            out = model(_tiny_inputs())
+            assert torch.isfinite(out["depth"]).all()
+        finally:
+            precision.set_operand_dtype(old)
+    finally:
+        sd["aggregator.frame_blocks.0.attn.proj.weight"] = good
+        model.load_state_dict(sd, strict=False)
+
+
+def test_load_state_dict_after_forward_rebuilds_packs():
+    """Packed 16-bit weights, dW copies, conv hi/lo packs and BN folds are keyed on the parameters' version: after a forward,
+    load_state_dict with different values must give exactly what a freshly built model gives."""
+    from oracle import weights
+
+    images = _tiny_inputs()
+    model = build_gpu_model("stress", 0)
+    a0 = model(images)["world_points"].clone()
+    model.load_state_dict(weights.fill_state_dict(schema(), seed=1, mode="stress", device="cuda"), strict=False)
+    b = {k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v]) for k, v in model(images).items()}
+    assert not torch.equal(b["world_points"], a0)
+    fresh = build_gpu_model("stress", 1)           # a new model object with the seed-1 weights
+    c = fresh(images)
+    for k in ("depth", "depth_conf", "world_points", "world_points_conf", "part_feat"):
+        assert torch.equal(b[k], c[k]), k
+    assert all(torch.equal(x, y) for x, y in zip(b["pose_enc"], c["pose_enc"]))
