@@ -74,6 +74,28 @@ class ViewShard:
         self._step(lambda: self._gather(out, kv_local))
         return out
 
+    def all_gather_kv_begin(self, kv_local: torch.Tensor):
+        """Start the K/V all-gather without making the compute stream wait for it: returns (kv_all, finish) where
+        `finish()` must be called before kv_all is read.  Between the two calls the caller runs the part of the global
+        attention that only needs this rank's own keys (layers/blocks.py), hiding that much of the transport.  Under graph
+        capture both halves are eager steps between graph segments."""
+        assert kv_local.is_contiguous()
+        out = self._buf("kv_all", (self.world * kv_local.shape[0], kv_local.shape[1]), kv_local)
+        state = {}
+
+        def start():
+            if self._flat():
+                state["work"] = dist.all_gather_into_tensor(out, kv_local, group=self.group, async_op=True)
+            else:
+                state["work"] = dist.all_gather(list(out.view(self.world, *kv_local.shape).unbind(0)), kv_local,
+                                                group=self.group, async_op=True)
+
+        def finish():
+            state.pop("work").wait()      # RCCL: the current stream waits for the collective; gloo: the host does
+
+        self._step(start)
+        return out, (lambda: self._step(finish))
+
     def _step(self, fn):
         """Run a collective now; under graph capture it is recorded as an eager step between two graph segments."""
         return fn() if self.ctl is None else self.ctl.eager(fn)

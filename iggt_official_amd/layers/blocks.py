@@ -214,6 +214,7 @@ class Block(nn.Module):
             precision.count_saturation("qkv", qkv)
         k_src, v_src, kv_rs, Nk, k_bs = qkv[:, C:], qkv[:, 2 * C:], 3 * C, tokens, tokens * 3 * C
         grouped = None
+        overlapped = False
         # static-bound softmax (csrc/attention_v3.hip): q leaves the q/k-norm kernel pre-scaled by scale * log2 e together
         # with the per-head maxima of |q| and |k|; not for the head-group pipelined gather (per-group launches)
         static = (self.attn.qk_norm and precision.static_softmax() and H == 16
@@ -242,12 +243,18 @@ class Block(nn.Module):
                 _C.qknorm_rope(qkv, qkv, kv_local, kv_local[:, C:], *qk_args, **sk)
                 if static:   # keys of the other ranks: the data-independent bound instead of this rank's maximum
                     qkmax[16:32].copy_(pk["k_bound"])
-                kv_all = gather(kv_local)
                 assert batch == 1
-                k_src, v_src, kv_rs, Nk, k_bs = kv_all, kv_all[:, C:], 2 * C, kv_all.shape[0], 0
+                if static and q_rows_per_wg == 0 and hasattr(kv_gather, "all_gather_kv_begin") and kv_gather.world > 1 \
+                        and precision.gather_overlap():
+                    overlapped = self._attend_overlapped(qkv, kv_local, kv_gather, qkmax, ao, ws, T, H, C)
+                else:
+                    kv_all = gather(kv_local)
+                    k_src, v_src, kv_rs, Nk, k_bs = kv_all, kv_all[:, C:], 2 * C, kv_all.shape[0], 0
         elif kv_gather is not None:
             raise _C.HipExtensionError("kv_gather needs a q/k-norm block")
-        if grouped is None:
+        if overlapped:
+            pass
+        elif grouped is None:
             with profiling.region("global_attn" if batch == 1 else "frame_attn", (batch, tokens, Nk)):
                 if static:
                     flags = ws.get("attn_flags", (batch * H * ((tokens + 127) // 128),), torch.int32, dev)
@@ -291,6 +298,33 @@ class Block(nn.Module):
         _C.gemm_h16(hid, pk["w_fc2"], x2d, bias=compensated_bias(ws, hid, pk["dw_fc2"], pk["b_fc2"]), gamma=pk["g2"],
                     accumulate=True)
         return x2d
+
+    def _attend_overlapped(self, qkv, kv_local, shard, qkmax, ao, ws, T, H, C):
+        """Multi-GPU global attention with the K/V all-gather hidden behind the attention over this rank's own keys.
+        Under the static softmax bound partial results over disjoint key sets simply add (csrc/attention_v3.hip), so the
+        keys are processed as segments: own keys (from kv_local, while the gather is in flight) -> slot 0; the ranks before
+        and after this one (from the gathered buffer) -> one slot per rank; one combine kernel folds the `world` slots and
+        runs the flagged-tile fallback over all keys."""
+        W, r = shard.world, shard.rank
+        dt, dev = qkv.dtype, qkv.device
+        o_part = ws.get("attn_opart", (W, 1, T, C), dt, dev)
+        l_part = ws.get("attn_lpart", (W, 1, H, T), torch.float32, dev)
+        flags = ws.get("attn_flags", (H * ((T + 127) // 128),), torch.int32, dev)
+        with profiling.region("global_attn", (1, T, W * T)):
+            kv_all, finish = shard.all_gather_kv_begin(kv_local)
+            _C.flash_attn_d64_static_partial(qkv, kv_local, kv_local[:, C:], 1, H, T, T, 0, 3 * C, 0, 2 * C, 0, 2 * C, qkmax,
+                                             o_part, l_part, 0, 1)
+            finish()
+            slot = 1
+            for first, n in ((0, r), (r + 1, W - 1 - r)):      # ranks before / after this one
+                if n > 0:
+                    seg = kv_all[first * T:(first + n) * T]
+                    _C.flash_attn_d64_static_partial(qkv, seg, seg[:, C:], 1, H, T, n * T, 0, 3 * C, 0, 2 * C, 0, 2 * C,
+                                                     qkmax, o_part, l_part, slot, n)
+                    slot += n
+            _C.flash_attn_d64_static_combine(o_part, l_part, W, qkv, kv_all, kv_all[:, C:], ao, 1, H, T, W * T, 0, 3 * C, 0,
+                                             2 * C, 0, 2 * C, 0, C, flags)
+        return True
 
     def forward(self, x: torch.Tensor, pos=None) -> torch.Tensor:
         """Reference signature (block.py:81): x [B, N, C] -> new tensor.  `pos` must be the standard

@@ -76,6 +76,20 @@ def set_static_softmax(on: bool) -> None:
     _static_softmax = bool(on)
 
 
+# Multi-GPU: hide the K/V all-gather behind the attention over a rank's own keys (layers/blocks.py _attend_overlapped; needs
+# the static softmax).  IGGT_GATHER_OVERLAP=0 restores gather -> one attention launch.
+_gather_overlap = os.environ.get("IGGT_GATHER_OVERLAP", "1") != "0"
+
+
+def gather_overlap() -> bool:
+    return _gather_overlap
+
+
+def set_gather_overlap(on: bool) -> None:
+    global _gather_overlap
+    _gather_overlap = bool(on)
+
+
 # fp16 range telemetry (debug): IGGT_DEBUG_SATURATION=1 makes the block engine count, after every kernel that stores 16-bit
 # activations (LayerNorm output, qkv, attention output, MLP hidden), the entries that were clamped to +-65504 or are not
 # finite (csrc/elementwise.hip count_saturated_kernel).  fp16 stores never produce inf -- they clamp -- so a silent

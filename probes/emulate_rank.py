@@ -32,6 +32,9 @@ class FakeShard:
     def all_gather_kv(self, kv):
         return kv.repeat(N, 1)
 
+    def all_gather_kv_begin(self, kv):     # overlap path (own keys first): same bytes land, no transport to hide here
+        return kv.repeat(N, 1), (lambda: None)
+
     def all_gather_rows(self, x):
         return x.repeat(N, *([1] * (x.dim() - 1)))
 

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, kv_groups, graphs, ret):
+def _worker(rank, world, port, case, kv_groups, graphs, overlap, ret):
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
@@ -35,8 +35,11 @@ def _worker(rank, world, port, case, kv_groups, graphs, ret):
     try:
         from conftest import load_golden
         from helpers import build_gpu_model, errors
+        from iggt_official_amd import precision
         from iggt_official_amd.dist import ViewShard
         from oracle import weights
+
+        precision.set_gather_overlap(overlap)
 
         torch.cuda.set_device(0)
         g = load_golden(case)
@@ -54,7 +57,8 @@ def _worker(rank, world, port, case, kv_groups, graphs, ret):
         torch.cuda.synchronize()
         if graphs:
             seg = next(iter(model._gcache._graphs.values()))[1]
-            assert seg.num_segments == 24 + 1 + 1, seg.num_segments   # 24 K/V gathers + 1 camera-token gather
+            # eager steps: per global block the K/V gather (begin + finish when it overlaps the own-key attention) + 1 camera gather
+            assert seg.num_segments == (48 if overlap else 24) + 1 + 1, seg.num_segments
             model.enable_graphs(False)
         res = {}
         for k in ("depth", "depth_conf", "world_points", "world_points_conf", "part_feat"):
@@ -66,13 +70,19 @@ def _worker(rank, world, port, case, kv_groups, graphs, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,kv_groups,graphs", [("tiny_s2_56_stress", 4, False), ("tiny_s2_56_stress", 1, False),
-                                                   ("tiny_s2_56_stress", 1, True)])
-def test_two_rank_sharded_forward_matches_reference(case, kv_groups, graphs):
+@pytest.mark.parametrize("case,kv_groups,graphs,overlap", [("tiny_s2_56_stress", 4, False, False),
+                                                           ("tiny_s2_56_stress", 1, False, False),
+                                                           ("tiny_s2_56_stress", 1, False, True),
+                                                           ("tiny_s2_56_stress", 1, True, True),
+                                                           ("tiny_s2_56_stress", 1, True, False)])
+def test_two_rank_sharded_forward_matches_reference(case, kv_groups, graphs, overlap):
+    """kv_groups 4: gather pipelined over head groups (online-max kernel); kv_groups 1: one gather, static-bound attention --
+    either gather -> one launch, or (overlap) own keys while the gather is in flight, then the other rank's keys, one slot
+    each, folded by the combine kernel; graphs: the same as hipGraph segments with the collectives as eager steps."""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), case, kv_groups, graphs, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), case, kv_groups, graphs, overlap, ret), nprocs=world, join=True)
     assert set(ret.keys()) == {0, 1}
     for rank, res in ret.items():
         for k, l2 in res.items():
