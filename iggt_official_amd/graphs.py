@@ -33,7 +33,10 @@ class SegmentedGraph:
     # -- capture -------------------------------------------------------------------------------------------------------
     def _begin(self):
         self._cur = torch.cuda.CUDAGraph()
-        self._cur.capture_begin(pool=self._pool)
+        # thread_local: an asynchronous collective started by an eager step may still be progressing on the transport's own
+        # thread / stream while the next segment is captured (gloo copies through the host; RCCL only launches kernels);
+        # this thread itself issues nothing but kernel launches and memsets between begin and end
+        self._cur.capture_begin(pool=self._pool, capture_error_mode="thread_local")
 
     def _end(self):
         self._cur.capture_end()
