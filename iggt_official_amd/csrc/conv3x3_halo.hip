@@ -1,0 +1,345 @@
+// 3x3 / stride 1 / pad 1 convolution with a spatial (halo) tile: the fast path of iggt_conv2d_nhwc_f32 for the layers that
+// carry ~85 % of the head FLOPs (layerN_rn, the ResidualConvUnit convolutions and output_conv1 of the DPT / part heads at
+// 74^2 ... 296^2, reference iggt/heads/dpt_head.py:345-357,369-411,117-120; SwinSA / SwinCA tails window_sa.py:383-391).
+//
+// Why a second convolution kernel.  conv_igemm.hip treats the convolution as a GEMM whose K runs tap-major: every 32-channel
+// slice of every tap is fetched from global memory, split into bf16 hi / lo and written to LDS again -- each activation is
+// loaded and split NINE times, and PMC showed the loader (6.4 VALU per MFMA, 31 % matrix-pipe busy), not the matrix pipe,
+// bounding it (profiles/r01_conv_pmc.txt).  Here a workgroup owns an 8 x 32 tile of output pixels:
+//   * per 32-channel slice the 10 x 34 HALO of input pixels is loaded and split ONCE (340 x 32 values instead of
+//     9 x 256 x 32) and all nine taps are row / column shifts of that one LDS image: an MFMA row block = one tile row of 32
+//     pixels, so the A fragment of tap (ky, kx) is the b128 read of halo pixels (y + ky, x + kx);
+//   * the weights of one (tap, slice) step -- BN x 32 x (hi + lo) = 32 KiB for BN = 256 -- stream through a 3-deep ring by
+//     LDS-DMA (global_load_lds, swizzle on the source address) behind counted vmcnt waits, one barrier per step;
+//   * a step is 48 MFMAs per wave (4 row blocks x 2 column blocks x 2 k-slices x 3 split products) against 24 ds_read_b128,
+//     4 DMA instructions and ~100 integer VALU ops: the matrix pipe is the only busy unit.
+// HBM / L2 bytes per MFMA drop 2.6x against the GEMM-shaped kernel (weights dominate; the halo is 1.3x the tile).
+// LDS images: 64-byte rows (32 bf16) with the 16-byte slot XOR ((row >> 2) & 3): conflict-free ds_read_b128 for any run of
+// 16 consecutive pixels (the key only depends on the pixel index, so a tap shift just moves the run).
+// Same numerics as conv_igemm PREC = 3 (split-bf16, three MFMAs per product, fp32 accumulate) and the same fused
+// ReLU-on-load / bias / activation / residual epilogue; tests/test_conv_gpu.py runs every case through both kernels.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+struct HaloParams {
+    const float* x;
+    const bf16_t* w_hi;
+    const bf16_t* w_lo;
+    const float* bias;
+    const float* res;
+    const float* res2;
+    float* y;
+    int Nimg, H, W, Cin, ldx, Cout, ldy, ldr;
+    int relu_in, relu_res, act;
+    int tiles_x, tiles_y, tiles_n;
+};
+
+constexpr int TH = 8, TW = 32;
+constexpr int HH = TH + 2, HW = TW + 2;
+constexpr int HALO_PX = HH * HW;               // 340
+constexpr int HALO_PLANE = HALO_PX * 64;       // one bf16 plane of a 32-channel slice
+constexpr int HALO_BYTES = 2 * HALO_PLANE;     // hi + lo
+constexpr int HALO_ITEMS = HALO_PX * 8;        // float4 groups per slice
+constexpr int HALO_ITERS = (HALO_ITEMS + 511) / 512;   // 6
+constexpr int NWBUF = 3;
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int N>
+IGGT_DEVINL void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BN>
+struct HaloTile {
+    static constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N, MI = TH / WAVES_M;
+    static constexpr int W_STAGE = 2 * BN * 64;                     // hi + lo rows of one (tap, slice)
+    static constexpr int NI = W_STAGE / (512 * 16);                 // DMA instructions per thread and step
+    static constexpr int EPI_BYTES = 128 * BN * 4;                  // 128 pixels per epilogue pass
+    static constexpr int MAIN_BYTES = HALO_BYTES + NWBUF * W_STAGE;
+    static constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+};
+
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p) {
+    using T = HaloTile<BN>;
+    constexpr int WAVES_N = T::WAVES_N, WAVES_M = T::WAVES_M, MI = T::MI, W_STAGE = T::W_STAGE, NI = T::NI;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* halo = smem;
+    char* wring = smem + HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int frow = lane & 31, fhalf = lane >> 5;
+
+    int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = v % p.tiles_n;
+    v /= p.tiles_n;
+    const int tx = v % p.tiles_x;
+    v /= p.tiles_x;
+    const int ty = v % p.tiles_y, img = v / p.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = tn * BN;
+    const long Ktot = 9L * p.Cin;
+    const int nch = p.Cin >> 5, total = 9 * nch;
+    const float relu_floor = p.relu_in ? 0.f : -INFINITY;
+
+    // ---- halo staging: item = (pixel q, channel group g of 4); every thread always issues HALO_ITERS loads (clamped
+    //      addresses) so that the per-wave VMEM count is uniform ---------------------------------------------------------
+    const float* src_px[HALO_ITERS];
+    int dst_off[HALO_ITERS];
+    bool inb[HALO_ITERS], act_item[HALO_ITERS];
+#pragma unroll
+    for (int it = 0; it < HALO_ITERS; ++it) {
+        int item = it * 512 + tid;
+        act_item[it] = item < HALO_ITEMS;
+        item = act_item[it] ? item : HALO_ITEMS - 1;
+        const int q = item >> 3, g = item & 7;
+        const int hy = q / HW, hx = q - hy * HW;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        inb[it] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const int cy = inb[it] ? iy : 0, cx = inb[it] ? ix : 0;
+        src_px[it] = p.x + (((long)img * p.H + cy) * p.W + cx) * p.ldx + 4 * g;
+        dst_off[it] = q * 64 + ((((g >> 1) ^ (q >> 2)) & 3) << 4) + (g & 1) * 8;
+    }
+    f32x4 hreg[HALO_ITERS];
+    auto halo_issue = [&](int c) {
+#pragma unroll
+        for (int it = 0; it < HALO_ITERS; ++it) hreg[it] = *reinterpret_cast<const f32x4*>(src_px[it] + c * 32);
+    };
+    auto halo_write = [&]() {
+#pragma unroll
+        for (int it = 0; it < HALO_ITERS; ++it) {
+            if (!act_item[it]) continue;
+            u32x2 hi, lo;
+            float xv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = inb[it] ? fmaxf(hreg[it][e], relu_floor) : 0.f;
+            hi[0] = pack_bf16x2(xv[0], xv[1]);
+            hi[1] = pack_bf16x2(xv[2], xv[3]);
+            lo[0] = pack_bf16x2(xv[0] - bf16_lo(hi[0]), xv[1] - bf16_hi(hi[0]));
+            lo[1] = pack_bf16x2(xv[2] - bf16_lo(hi[1]), xv[3] - bf16_hi(hi[1]));
+            *reinterpret_cast<u32x2*>(halo + dst_off[it]) = hi;
+            *reinterpret_cast<u32x2*>(halo + HALO_PLANE + dst_off[it]) = lo;
+        }
+    };
+
+    // ---- weight DMA: step s = (slice c = s / 9, tap t = s % 9); piece P = (k * 8 + wave) * 64 + lane of the stage image
+    //      [plane][BN rows][4 slots of 16 B]; the slot swizzle is applied to the SOURCE address ----------------------------
+    const bf16_t* wsrc[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int P = (k * 8 + wave) * 64 + lane;
+        const int plane = P / (BN * 4), rp = P - plane * (BN * 4);
+        const int n = rp >> 2, sl = rp & 3;
+        int gn = n0 + n;
+        gn = gn < p.Cout ? gn : p.Cout - 1;
+        wsrc[k] = (plane ? p.w_lo : p.w_hi) + (long)gn * Ktot + ((sl ^ (n >> 2)) & 3) * 8;
+    }
+    auto dma_w = [&](int s) {
+        const int c = s / 9, t = s - c * 9;
+        const int koff = t * p.Cin + c * 32;
+        char* dst = wring + (s % NWBUF) * W_STAGE;
+#pragma unroll
+        for (int k = 0; k < NI; ++k)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[k] + koff), (lptr_t*)(dst + (k * 8 + wave) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // lane-dependent LDS offsets of the B fragments (row n = wn * 64 + j * 32 + frow)
+    int boff[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = wn * 64 + j * 32 + frow;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) boff[j][kc] = n * 64 + ((((2 * kc + fhalf) ^ (n >> 2)) & 3) << 4);
+    }
+    const int q_base = (wm * MI) * HW + frow;   // halo pixel of (tile row wm * MI, column frow) for tap (0, 0)
+
+    auto compute = [&](int s) {
+        const int t = s % 9;
+        const int ky = t / 3, kx = t - ky * 3;
+        const char* wb = wring + (s % NWBUF) * W_STAGE;
+        const int q0 = q_base + ky * HW + kx;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            bf16x8 ah[MI], al[MI], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int q = q0 + i * HW;
+                const int off = q * 64 + ((((2 * kc + fhalf) ^ (q >> 2)) & 3) << 4);
+                ah[i] = *reinterpret_cast<const bf16x8*>(halo + off);
+                al[i] = *reinterpret_cast<const bf16x8*>(halo + HALO_PLANE + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j][kc]);
+                bl[j] = *reinterpret_cast<const bf16x8*>(wb + BN * 64 + boff[j][kc]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = mfma32(ah[i], bh[j], acc[i][j]);
+                    acc[i][j] = mfma32(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = mfma32(al[i], bh[j], acc[i][j]);
+                }
+        }
+    };
+
+    // ---- prologue ---------------------------------------------------------------------------------------------------------
+    halo_issue(0);
+    dma_w(0);
+    if (total > 1) dma_w(1);
+    halo_write();                                   // (the compiler waits for the halo loads here)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // ---- main loop: one barrier per step; step s waits for its own weights only (the DMA of step s + 1 stays in flight) ----
+#pragma unroll 1
+    for (int s = 0; s < total; ++s) {
+        const int c = s / 9, t = s - c * 9;
+        if (s + 1 < total) wait_vm<NI>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();               // W(s) landed in every wave; every wave finished step s - 1
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);          // nothing of this step may be scheduled above the barrier
+        if (t == 0 && c > 0) {
+            halo_write();                           // slice c (loaded during slice c - 1) replaces the halo all waves are done with
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (s + 2 < total) dma_w(s + 2);
+        if (t == 0 && c + 1 < nch) halo_issue(c + 1);
+        compute(s);
+        __builtin_amdgcn_sched_barrier(0);          // ... and nothing of it below the next step's wait
+    }
+
+    // ---- epilogue: 128 pixels per pass through LDS, then whole contiguous channel runs per pixel -----------------------
+    wait_vm<0>();
+    __syncthreads();
+    float* stile = reinterpret_cast<float*>(smem);
+    constexpr int C4 = BN / 4;
+    constexpr int WM_PER_PASS = WAVES_M / 2;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wm / WM_PER_PASS == pass) {
+            const int rbase = (wm % WM_PER_PASS) * MI * 32;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stile[(rbase + i * 32 + mfma32_row(r, lane)) * BN + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+        }
+        __syncthreads();
+        constexpr int EB = 4;
+#pragma unroll 1
+        for (int idx0 = tid; idx0 < 128 * C4; idx0 += EB * 512) {
+            long pixs[EB];
+            bool ok[EB];
+            f32x4 r1[EB], r2[EB];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const int idx = idx0 + u * 512;
+                const int row = idx / C4, c4 = idx - row * C4;
+                const int m = pass * 128 + row;
+                const int oy = oy0 + (m >> 5), ox = ox0 + (m & 31);
+                const int n = n0 + c4 * 4;
+                ok[u] = idx < 128 * C4 && oy < p.H && ox < p.W && n < p.Cout;
+                pixs[u] = ok[u] ? ((long)img * p.H + oy) * p.W + ox : 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { r1[u][e] = 0.f; r2[u][e] = 0.f; }
+                if (ok[u] && p.res) {
+                    r1[u] = *reinterpret_cast<const f32x4*>(p.res + pixs[u] * p.ldr + n);
+                    if (p.res2) r2[u] = *reinterpret_cast<const f32x4*>(p.res2 + pixs[u] * p.ldr + n);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                if (!ok[u]) continue;
+                const int idx = idx0 + u * 512;
+                const int row = idx / C4, c4 = idx - row * C4;
+                const int n = n0 + c4 * 4;
+                f32x4 vv = *reinterpret_cast<const f32x4*>(stile + row * BN + c4 * 4);
+                if (p.bias) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vv[e] += b4[e];
+                }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vv[e] = fmaxf(vv[e], 0.f);
+                } else if (p.act == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vv[e] = vv[e] > 0.f ? vv[e] : 0.01f * vv[e];
+                } else if (p.act == 3) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vv[e] = 0.5f * vv[e] * (1.0f + erff(vv[e] * 0.70710678118654752440f));
+                }
+                if (p.res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vv[e] += (p.relu_res ? fmaxf(r1[u][e], 0.f) : r1[u][e]) + r2[u][e];
+                }
+                *reinterpret_cast<f32x4*>(p.y + pixs[u] * p.ldy + n) = vv;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int BN>
+int launch_halo(const HaloParams& p_in, hipStream_t st) {
+    using T = HaloTile<BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    HaloParams p = p_in;
+    p.tiles_x = (p.W + TW - 1) / TW;
+    p.tiles_y = (p.H + TH - 1) / TH;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    const long grid = (long)p.Nimg * p.tiles_y * p.tiles_x * p.tiles_n;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN>), dim3((unsigned)grid), dim3(512), T::SMEM, st, p);
+    return 0;
+}
+
+}  // namespace
+
+// Called by iggt_conv2d_nhwc_f32 (conv_igemm.hip).  Returns -100 when the problem is not one this kernel is built for.
+int iggt_launch_conv3x3_halo(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
+                             const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg, int H, int W,
+                             int Cin, int Cout, int relu_in, int relu_res, int act, hipStream_t st) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("IGGT_CONV_HALO");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (!on || w_lo == nullptr || (Cin % 32) != 0 || (Cout % 128) != 0 || (ldx % 4) || (ldy % 4) || (res && (ldr % 4)))
+        return -100;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)res2 | (uintptr_t)bias) % 16) return -100;
+    // small maps: the 8 x 32 tile wastes too much of its halo / MFMA rows (37 x 37 and below stay on the GEMM-shaped kernel)
+    if (W < 48 || H < 16 || (long)Nimg * H * W < 4096) return -100;
+    HaloParams p;
+    p.x = x; p.w_hi = (const bf16_t*)w_hi; p.w_lo = (const bf16_t*)w_lo; p.bias = bias; p.res = res; p.res2 = res2; p.y = y;
+    p.Nimg = Nimg; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldy = ldy; p.ldr = ldr;
+    p.relu_in = relu_in; p.relu_res = relu_res; p.act = act;
+    p.tiles_x = p.tiles_y = p.tiles_n = 0;
+    return (Cout % 256) == 0 ? launch_halo<256>(p, st) : launch_halo<128>(p, st);
+}

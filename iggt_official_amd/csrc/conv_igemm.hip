@@ -429,6 +429,11 @@ int launch(const ConvParams& p, hipStream_t st) {
 
 }  // namespace
 
+// 3x3 / stride 1 / pad 1 fast path with a spatial halo tile (conv3x3_halo.hip); -100: not applicable
+int iggt_launch_conv3x3_halo(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
+                             const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg, int H, int W,
+                             int Cin, int Cout, int relu_in, int relu_res, int act, hipStream_t st);
+
 extern "C" int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
                                     const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg, int Hi, int Wi,
                                     int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_y,
@@ -452,6 +457,16 @@ extern "C" int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, c
     p.M = (long)Nimg * Ho * Wo;
     p.tiles_n = 0;
     hipStream_t st = (hipStream_t)stream;
+    if (prec == 3 && KH == 3 && KW == 3 && stride == 1 && pad_y == 1 && pad_x == 1 && ps == 1 && osy == 1 && osx == 1 &&
+        ooy == 0 && oox == 0 && Ho == Hi && Wo == Wi && Hout == Hi && Wout == Wi && cout_phys == Cout) {
+        const int hrc = iggt_launch_conv3x3_halo(x, ldx, w_hi, w_lo, bias, res, res2, ldr, y, ldy, Nimg, Hi, Wi, Cin, Cout,
+                                                 relu_in, relu_res, act, st);
+        if (hrc != -100) {
+            if (hrc) return hrc;
+            IGGT_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     // 256x256 tile (8 waves, one workgroup per CU): every split activation is used for 256 output channels instead of
     // 128 -- half the loader work (loads, hi/lo split, LDS writes) per MFMA.  Only when the grid still fills the chip.
     static int big = -1, cus = 256;

@@ -99,8 +99,13 @@ __global__ __launch_bounds__(512) void linear_f32_kernel(const LinParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Attention, fp32.  256 threads = 64 query rows x 4 threads; thread q of a row owns the float4 chunks 4 i + q of the head
-// dimension (so that the four threads of a row read 64 contiguous bytes of a K / V row: conflict-free LDS broadcast).
+// Attention, fp32, on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate, 157 TFLOP/s).
+// Same dataflow as the 16-bit flash kernel, one precision class up: a wave owns 32 query rows, S^T[key][q] = K . Q^T
+// (A = K rows from LDS, B = Q held in registers) so a lane owns one query column and the online softmax is lane-local plus
+// one exchange with lane ^ 32; the exponentiated accumulator registers feed O^T = V^T . P^T directly as the B operand --
+// register j of lane half h is key (j & 3) + 8 (j >> 2) + 4 h, so the A operand of MFMA j reads exactly those two V rows.
+// (A first version did the dot products on the VALU with 4 threads per row and two LDS shuffles per key: 7.0 ms for the
+// part head's cross attention at 8 x 504^2 -- 8 x 8 heads x 1296^2 x 32 -- against ~0.15 ms of matrix-pipe time.)
 struct AttnF32Params {
     const float* q; const float* k; const float* v; float* o;
     long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;   // elements; head h at column offset h * D
@@ -110,81 +115,83 @@ struct AttnF32Params {
 
 template <int D>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32Params p) {
-    constexpr int NC = D / 16;                 // float4 chunks per thread
+    constexpr int KP = D + 1;                  // padded K row: the A-operand read (lane -> key row) is conflict-free
     extern __shared__ __attribute__((aligned(16))) float smf[];
-    float* Ks = smf;
-    float* Vs = smf + 64 * D;
-    const int tid = threadIdx.x, row = tid >> 2, qq = tid & 3;
+    float* Ks = smf;                           // [32][D + 1]
+    float* Vs = smf + 32 * KP;                 // [32][D]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z;
-    int qr = blockIdx.x * 64 + row;
+    int qr = blockIdx.x * 128 + wave * 32 + r;
     const bool valid = qr < p.Nq;
     qr = valid ? qr : p.Nq - 1;
     const float* qp = p.q + (long)b * p.q_bs + (long)qr * p.q_rs + h * D;
-    f32x4 qv[NC], o[NC];
+    float qreg[D / 2];                         // B operand of MFMA j: Q[q][2 j + hh], pre-scaled by scale * log2 e
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        qv[i] = *reinterpret_cast<const f32x4*>(qp + 4 * (4 * i + qq));
+    for (int j = 0; j < D / 2; ++j) qreg[j] = qp[2 * j + hh] * p.scale_log2;
+    f32x16 o[D / 32];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { qv[i][e] *= p.scale_log2; o[i][e] = 0.f; }
-    }
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
     float m = -INFINITY, l = 0.f;
     const float* kb = p.k + (long)b * p.k_bs + h * D;
     const float* vb = p.v + (long)b * p.v_bs + h * D;
-    for (int t0 = 0; t0 < p.Nk; t0 += 64) {
+    for (int t0 = 0; t0 < p.Nk; t0 += 32) {
         __syncthreads();
-        for (int i = tid; i < 64 * (D / 4); i += 256) {
+        for (int i = tid; i < 32 * (D / 4); i += 256) {
             const int kr = i / (D / 4), c4 = i - kr * (D / 4);
             int kg = t0 + kr;
             kg = kg < p.Nk ? kg : p.Nk - 1;
-            *reinterpret_cast<f32x4*>(Ks + kr * D + 4 * c4) = *reinterpret_cast<const f32x4*>(kb + (long)kg * p.k_rs + 4 * c4);
+            const f32x4 kk = *reinterpret_cast<const f32x4*>(kb + (long)kg * p.k_rs + 4 * c4);
+            Ks[kr * KP + 4 * c4] = kk[0]; Ks[kr * KP + 4 * c4 + 1] = kk[1];
+            Ks[kr * KP + 4 * c4 + 2] = kk[2]; Ks[kr * KP + 4 * c4 + 3] = kk[3];
             *reinterpret_cast<f32x4*>(Vs + kr * D + 4 * c4) = *reinterpret_cast<const f32x4*>(vb + (long)kg * p.v_rs + 4 * c4);
         }
         __syncthreads();
-        const int nk = (p.Nk - t0) < 64 ? (p.Nk - t0) : 64;
-        for (int j0 = 0; j0 < nk; j0 += 4) {
-            float s[4];
+        f32x16 s;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float d = 0.f;
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
-                for (int i = 0; i < NC; ++i) {
-                    const f32x4 kk = *reinterpret_cast<const f32x4*>(Ks + (j0 + e) * D + 4 * (4 * i + qq));
-                    d += qv[i][0] * kk[0] + qv[i][1] * kk[1] + qv[i][2] * kk[2] + qv[i][3] * kk[3];
-                }
-                d += __shfl_xor(d, 1, 64);
-                d += __shfl_xor(d, 2, 64);
-                s[e] = (j0 + e < nk) ? d : -INFINITY;
-            }
-            const float mn = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), m);
-            const float alpha = __builtin_amdgcn_exp2f(m - mn);   // m = -inf on the first step: exp2(-inf) = 0
-            m = mn;
-            float pe[4];
+        for (int j = 0; j < D / 2; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[r * KP + 2 * j + hh], qreg[j], s, 0, 0, 0);
+        const int nk = p.Nk - t0;              // valid keys in this tile (>= 1)
+        float mx = -INFINITY;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pe[e] = __builtin_amdgcn_exp2f(s[e] - mn);
-            l = l * alpha + (pe[0] + pe[1]) + (pe[2] + pe[3]);
+        for (int e = 0; e < 16; ++e) {
+            const int key = (e & 3) + 8 * (e >> 2) + 4 * hh;
+            s[e] = key < nk ? s[e] : -INFINITY;
+            mx = fmaxf(mx, s[e]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);     // first tile: exp2(-inf) = 0
+        m = mn;
+        float ls = 0.f;
 #pragma unroll
-            for (int i = 0; i < NC; ++i) {
+        for (int e = 0; e < 16; ++e) {
+            s[e] = __builtin_amdgcn_exp2f(s[e] - mn);
+            ls += s[e];
+        }
+        l = l * alpha + ls;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) o[i][c] *= alpha;
+        for (int i = 0; i < D / 32; ++i) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const f32x4 vv = *reinterpret_cast<const f32x4*>(Vs + (j0 + e) * D + 4 * (4 * i + qq));
+            for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[i][c] += pe[e] * vv[c];
-                }
+            for (int e = 0; e < 16; ++e) {
+                const int key = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * D + i * 32 + r], s[e], o[i], 0, 0, 0);
             }
         }
     }
+    l += __shfl_xor(l, 32, 64);
     if (valid) {
         const float inv = 1.f / l;
         float* op = p.o + (long)b * p.o_bs + (long)qr * p.o_rs + h * D;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            f32x4 w;
+        for (int i = 0; i < D / 32; ++i)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) w[c] = o[i][c] * inv;
-            *reinterpret_cast<f32x4*>(op + 4 * (4 * i + qq)) = w;
-        }
+            for (int e = 0; e < 16; ++e) op[i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh] = o[i][e] * inv;
     }
 }
 
@@ -316,20 +323,12 @@ extern "C" int iggt_attn_f32(const float* q, const float* k, const float* v, flo
     if ((q_rs | k_rs | v_rs | o_rs | q_bs | k_bs | v_bs | o_bs) % 4) return -2;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16) return -2;
     AttnF32Params p{q, k, v, o, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, B, H, Nq, Nk, scale * 1.4426950408889634f};
-    const dim3 grid((Nq + 63) / 64, H, B), block(256);
-    const size_t lds = 2 * 64 * (size_t)head_dim * sizeof(float);
+    const dim3 grid((Nq + 127) / 128, H, B), block(256);
+    const size_t lds = 32 * (size_t)(2 * head_dim + 1) * sizeof(float);
     if (head_dim == 32) hipLaunchKernelGGL(attn_f32_kernel<32>, grid, block, lds, (hipStream_t)stream, p);
     else if (head_dim == 64) hipLaunchKernelGGL(attn_f32_kernel<64>, grid, block, lds, (hipStream_t)stream, p);
-    else if (head_dim == 128) {
-        static bool attr = false;
-        if (!attr) {
-            const hipError_t e = hipFuncSetAttribute((const void*)attn_f32_kernel<128>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-            attr = true;
-        }
-        hipLaunchKernelGGL(attn_f32_kernel<128>, grid, block, lds, (hipStream_t)stream, p);
-    } else return -3;
+    else if (head_dim == 128) hipLaunchKernelGGL(attn_f32_kernel<128>, grid, block, lds, (hipStream_t)stream, p);
+    else return -3;
     IGGT_CHECK_LAUNCH();
     return 0;
 }

@@ -58,6 +58,41 @@ def test_conv_fused_relu_residuals_and_acts():
         assert _err(y.permute(0, 3, 1, 2), fn(base))[0] < 2e-5, act
 
 
+@pytest.mark.parametrize("cin,cout,n,hw", [(256, 256, 2, (74, 74)), (256, 128, 1, (70, 100)), (64, 128, 3, (16, 50)),
+                                           (512, 256, 1, (37, 74)), (128, 512, 2, (24, 48)), (32, 256, 1, (148, 148))])
+def test_conv3x3_halo_tile_kernel(cin, cout, n, hw):
+    """Shapes that take the spatial-halo kernel (csrc/conv3x3_halo.hip: 3x3 / s1 / p1, Cout in 128N, maps >= 16 x 48): ragged
+    tiles in both directions, one to sixteen 32-channel slices, both column-tile widths (256 / 128), every fused epilogue
+    feature -- against fp64 and against the GEMM-shaped kernel on a sub-threshold crop of the same problem."""
+    from iggt_official_amd.heads import convops as co
+
+    conv = nn.Conv2d(cin, cout, 3, 1, 1).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(_mk(conv.weight.shape, 21, (cin * 9) ** -0.5))
+        conv.bias.copy_(_mk(conv.bias.shape, 22, 0.1))
+    pc = co.pack_conv2d(conv)
+    x = _mk((n, hw[0], hw[1], cin), 23)
+    xd = x.permute(0, 3, 1, 2).double()
+    y = co.run(pc, x)
+    ref = F.conv2d(xd, conv.weight.double(), conv.bias.double(), 1, 1)
+    mx, l2 = _err(y.permute(0, 3, 1, 2), ref)
+    report(f"conv_halo_{cin}_{cout}_{hw[0]}x{hw[1]}", dict(max=mx, l2=l2))
+    assert mx < 2e-5, (mx, l2)
+    r1, r2 = _mk((n, hw[0], hw[1], cout), 24), _mk((n, hw[0], hw[1], cout), 25)
+    base = F.conv2d(F.relu(xd), conv.weight.double(), conv.bias.double(), 1, 1)
+    y = co.run(pc, x, relu_in=True, res=r1, relu_res=True, res2=r2)
+    want = base + F.relu(r1.permute(0, 3, 1, 2).double()) + r2.permute(0, 3, 1, 2).double()
+    assert _err(y.permute(0, 3, 1, 2), want)[0] < 2e-5
+    for act, fn in [(1, F.relu), (2, lambda t: F.leaky_relu(t, 0.01)), (3, F.gelu)]:
+        y = co.run(pc, x, relu_in=True, act=act)
+        assert _err(y.permute(0, 3, 1, 2), fn(base))[0] < 2e-5, act
+    # interior of the map == the GEMM-shaped kernel on a crop too narrow for the halo kernel (W < 48)
+    crop = x[:1, :, :40].contiguous()
+    yc = co.run(pc, crop)
+    yf = co.run(pc, x)
+    assert _err(yc[:, :, :38], yf[:1, :, :38])[0] < 2e-6
+
+
 def test_conv_bn_fold_and_channel_padding():
     from iggt_official_amd.heads import convops as co
 
