@@ -1,14 +1,15 @@
 """hipGraph replay of the forward pass (one process per GPU; matters for the per-rank forward of a multi-GPU run).
 
-A 32-view forward is ~2 500 kernel launches.  On one GPU they are hidden behind 400 ms of kernels, but the per-rank
-forward of an 8-GPU run (4 views, ~50 ms of kernels) is bound by the ~30 us of Python + ctypes every launch costs
-(measured: 75 ms of host time, probes/emulate_rank.py).  Every entry point of libiggt_hip.so only enqueues work on the
+A 32-view forward is ~2 500 kernel launches.  On one GPU they are hidden behind 380 ms of kernels, but the per-rank
+forward of an 8-GPU run (4 views, ~65 ms of kernels) has 19-75 ms of Python + ctypes launch time next to it depending on
+the host (probes/emulate_rank.py: 0.6 ms with graphs).  Every entry point of libiggt_hip.so only enqueues work on the
 stream it is given (include/iggt_hip.h), so the whole forward can be captured once per input shape and replayed with a
 handful of host calls.
 
 Collectives are NOT captured: RCCL all-gathers stay ordinary eager calls between graph segments (`SegmentedGraph.eager`),
 so the capture never depends on the collective library's graph support and a communicator error surfaces as a normal
-exception.  A sharded 24-block forward becomes 25 graph segments + 24 all-gathers (+ 1 camera-token gather).
+exception.  A sharded 24-block forward becomes 26 graph segments around 24 K/V all-gathers and the camera-token gather
+(50 when the gather overlaps the own-key attention: its start and its completion are separate eager steps).
 
 Contract of a graphed forward (same as any CUDA/HIP-graph runtime): inputs are copied into a static buffer, outputs live
 in static buffers that the NEXT call overwrites -- clone what must survive.  Graphs are keyed by input shape / operand
