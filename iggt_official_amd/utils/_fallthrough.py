@@ -21,9 +21,17 @@ def fill_missing(package: str, module: str, namespace: dict) -> None:
         if not os.path.exists(path):
             continue
         try:
-            spec = importlib.util.spec_from_file_location(f"_iggt_reference_{package.replace('.', '_')}_{module}", path)
+            # loaded as a private sibling inside the package, so that the reference module's relative imports
+            # (`from .rotation import ...`) resolve -- through the same extended package path
+            name = f"{package}._reference_{module}"
+            spec = importlib.util.spec_from_file_location(name, path)
             mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)
+            sys.modules[name] = mod
+            try:
+                spec.loader.exec_module(mod)
+            except BaseException:
+                sys.modules.pop(name, None)
+                raise
         except Exception:  # noqa: BLE001  (the reference module may need packages that are not installed)
             return
         for k, v in vars(mod).items():

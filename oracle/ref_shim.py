@@ -57,6 +57,14 @@ def install():
     spec = importlib.machinery.ModuleSpec("iggt", None, is_package=True)
     spec.submodule_search_locations = [os.path.join(REF_ROOT, "iggt")]
     sys.modules["iggt"] = importlib.util.module_from_spec(spec)
+    # inspect.getmodule() (torch.library calls it while the reference imports) keeps a file-name cache per module name; an
+    # `iggt*` entry left by the product alias makes it call getfile() on the reference's file-less namespace packages
+    import inspect
+
+    cache = getattr(inspect, "_filesbymodname", None)
+    if isinstance(cache, dict):
+        for k in [k for k in cache if k == "iggt" or k.startswith("iggt.")]:
+            del cache[k]
     if REF_ROOT not in sys.path:
         sys.path.append(REF_ROOT)   # for the reference's own top-level helpers; `iggt` itself no longer uses sys.path
 

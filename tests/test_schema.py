@@ -34,8 +34,10 @@ def test_relative_position_buffers_match_reference():
 
 
 def test_alias_package_falls_through_to_reference_for_off_path_modules():
-    """demo.py imports iggt.models.vggt (provided here) AND iggt.utils.* (not provided: off the hot path).  With this
-    repository in front of a reference checkout on PYTHONPATH the first resolves here, the second to the reference."""
+    """demo.py imports iggt.models.vggt and iggt.utils.{load_fn,pose_enc,geometry} (provided here) AND other iggt.utils.*
+    modules (not provided: off the hot path).  With this repository in front of a reference checkout on PYTHONPATH the first
+    group resolves here, the rest to the reference -- and the functions of pose_enc.py this repository does not re-implement
+    are filled in from the reference's module of the same name."""
     import os
     import subprocess
     import sys
@@ -46,11 +48,15 @@ def test_alias_package_falls_through_to_reference_for_off_path_modules():
 
         pytest.skip("no reference checkout on this machine")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import iggt.models.vggt as v, iggt.utils.pose_enc as pe, iggt.heads.dpt_head as d;"
-            "print(v.__file__); print(pe.__file__); print(d.__file__)")
+    code = ("import iggt.models.vggt as v, iggt.utils.rotation as rot, iggt.heads.dpt_head as d, iggt.utils.pose_enc as pe, "
+            "utils.model as um;"
+            "print(v.__file__); print(rot.__file__); print(d.__file__); print(pe.__file__); print(um.__file__);"
+            "print(pe.pose_encoding_to_extri_intri.__module__); print(pe.extri_intri_to_pose_encoding.__module__)")
     env = dict(os.environ, PYTHONPATH=root + os.pathsep + ref)
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = out.stdout.strip().splitlines()[-3:]
-    assert lines[0].startswith(root) and lines[2].startswith(root), lines
+    lines = out.stdout.strip().splitlines()[-7:]
+    assert lines[0].startswith(root) and lines[2].startswith(root) and lines[3].startswith(root) and lines[4].startswith(root)
     assert lines[1].startswith(ref), lines
+    assert lines[5] == "iggt_official_amd.utils.pose_enc", lines       # the hot-path function: this repository's
+    assert lines[6] == "iggt.utils._reference_pose_enc", lines                 # an off-path one: the reference's, filled in
