@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -91,6 +91,14 @@ _SIGNATURES = {
                                _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p],
     "iggt_u8hwc_to_f32chw": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                              _c_int, _c_float, _c_void_p],
+    "iggt_knn_morton_codes": [_c_void_p, _c_long, _c_float, _c_float, _c_float, _c_float, _c_void_p, _c_void_p],
+    "iggt_knn_search": [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+    "iggt_knn_mean_features_f32": [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p],
+    "iggt_moments_f32": [_c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p],
+    "iggt_moments_width": [_c_int],
+    "iggt_project3_f32": [_c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "iggt_stretch3_f32": [_c_void_p, _c_long, _c_void_p, _c_void_p],
+    "iggt_nn1_label_f32": [_c_void_p, _c_long, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "iggt_count_saturated_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "iggt_write_special_tokens": [_c_void_p, _c_long, _c_long, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_void_p],
@@ -578,3 +586,106 @@ def count_saturated(x, counter):
     rc = load().iggt_count_saturated_h16(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], int(x.dtype == torch.float16),
                                          counter.data_ptr(), _stream())
     _check(rc, "iggt_count_saturated_h16")
+
+
+# ---- post-processing behind the forward path (csrc/postprocess.hip) -----------------------------------------------------
+def _f32c(*ts):
+    for t in ts:
+        assert t.dtype == torch.float32 and t.is_contiguous(), "fp32 contiguous tensors expected"
+
+
+def knn_morton_codes(points, center, inv_cell):
+    """points fp32 [M,3] (device) -> int32 [M] Morton codes on a 1024^3 grid around `center` (3 floats), cell 1/inv_cell."""
+    _dev(points)
+    _f32c(points)
+    M = points.shape[0]
+    codes = torch.empty(M, dtype=torch.int32, device=points.device)
+    rc = load().iggt_knn_morton_codes(points.data_ptr(), M, float(center[0]), float(center[1]), float(center[2]),
+                                      float(inv_cell), codes.data_ptr(), _stream())
+    _check(rc, "iggt_knn_morton_codes")
+    return codes
+
+
+def knn_search(points, order, k, want_dist=False):
+    """Exact kNN (self excluded) of points fp32 [M,3] given order = argsort of their Morton codes (int64 [M]).
+    -> idx int32 [M,k] (ascending distance, -1 = no such neighbour) and, on request, squared distances fp32 [M,k]."""
+    _dev(points, order)
+    _f32c(points)
+    assert order.dtype == torch.int64 and order.is_contiguous() and order.shape[0] == points.shape[0]
+    M = points.shape[0]
+    nt = (M + 255) // 256
+    ws = torch.empty(nt * 256 * 4, dtype=torch.float32, device=points.device)
+    boxes = torch.empty(nt * 6, dtype=torch.float32, device=points.device)
+    idx = torch.empty(M, k, dtype=torch.int32, device=points.device)
+    d2 = torch.empty(M, k, dtype=torch.float32, device=points.device) if want_dist else None
+    rc = load().iggt_knn_search(points.data_ptr(), order.data_ptr(), M, int(k), ws.data_ptr(), boxes.data_ptr(),
+                                idx.data_ptr(), _ptr(d2), _stream())
+    _check(rc, "iggt_knn_search")
+    return (idx, d2) if want_dist else idx
+
+
+def knn_mean_features(feat, idx):
+    """feat fp32 [M,F], idx int32 [M,k] -> fp32 [M,F]: mean of the valid neighbours' features (0 where none)."""
+    _dev(feat, idx)
+    _f32c(feat)
+    assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.shape[0] == feat.shape[0]
+    out = torch.empty_like(feat)
+    rc = load().iggt_knn_mean_features_f32(feat.data_ptr(), idx.data_ptr(), feat.shape[0], idx.shape[1], feat.shape[1],
+                                           out.data_ptr(), _stream())
+    _check(rc, "iggt_knn_mean_features_f32")
+    return out
+
+
+def moments(x, shift, nblocks=512):
+    """x fp32 [M,C] (C <= 16), shift fp32 [C] -> (sum(x - shift) fp64 [C], sum((x-shift)(x-shift)^T) fp64 [C,C])."""
+    _dev(x, shift)
+    _f32c(x, shift)
+    M, C = x.shape
+    width = load().iggt_moments_width(C)
+    if width < 0:
+        raise HipExtensionError(f"iggt_moments_f32 supports at most 16 channels (got {C})")
+    nblocks = max(1, min(nblocks, (M + 255) // 256))
+    part = torch.empty(nblocks, width, dtype=torch.float32, device=x.device)
+    rc = load().iggt_moments_f32(x.data_ptr(), M, C, shift.data_ptr(), part.data_ptr(), nblocks, _stream())
+    _check(rc, "iggt_moments_f32")
+    tot = part.double().sum(0)
+    ct = 4 if C <= 4 else (8 if C <= 8 else 16)
+    s1 = tot[:C].clone()
+    iu = torch.triu_indices(ct, ct, device=x.device)
+    g = torch.zeros(ct, ct, dtype=torch.float64, device=x.device)
+    g[iu[0], iu[1]] = tot[ct:]
+    g = g + g.T - torch.diag(torch.diagonal(g))
+    return s1, g[:C, :C].contiguous()
+
+
+def project3(x, v):
+    """x fp32 [M,C] @ v fp32 [C,3] -> fp32 [M,3]."""
+    _dev(x, v)
+    _f32c(x, v)
+    assert v.shape == (x.shape[1], 3)
+    out = torch.empty(x.shape[0], 3, dtype=torch.float32, device=x.device)
+    rc = load().iggt_project3_f32(x.data_ptr(), x.shape[0], x.shape[1], v.data_ptr(), out.data_ptr(), _stream())
+    _check(rc, "iggt_project3_f32")
+    return out
+
+
+def stretch3(img, lohi):
+    """In place: img fp32 [M,3] channel j -> clamp((v - lohi[j]) / (lohi[3+j] - lohi[j]), 0, 1) (0.5 if degenerate)."""
+    _dev(img, lohi)
+    _f32c(img, lohi)
+    assert img.shape[1] == 3 and lohi.numel() == 6
+    rc = load().iggt_stretch3_f32(img.data_ptr(), img.shape[0], lohi.data_ptr(), _stream())
+    _check(rc, "iggt_stretch3_f32")
+    return img
+
+
+def nn1_label(query, ref, ref_labels):
+    """labels int32 [Mq] of the nearest (first minimum of the squared distance) row of ref fp32 [Mr,C] for every row of query."""
+    _dev(query, ref, ref_labels)
+    _f32c(query, ref)
+    assert ref_labels.dtype == torch.int32 and ref_labels.is_contiguous() and query.shape[1] == ref.shape[1]
+    out = torch.empty(query.shape[0], dtype=torch.int32, device=query.device)
+    rc = load().iggt_nn1_label_f32(query.data_ptr(), query.shape[0], ref.data_ptr(), ref.shape[0], ref.shape[1],
+                                   ref_labels.data_ptr(), out.data_ptr(), _stream())
+    _check(rc, "iggt_nn1_label_f32")
+    return out

@@ -266,6 +266,40 @@ int iggt_resize_bicubic_u8(const void* in, int Hi, int Wi, const int* hbounds, c
 int iggt_u8hwc_to_f32chw(const void* src, int Hs, int Ws, float* dst, int Hd, int Wd, int crop_y, int crop_x, int pad_y,
                          int pad_x, int h, int w, float pad_value, void* stream);
 
+/* ---- post-processing behind the forward path (csrc/postprocess.hip; reference iggt/utils/misc.py, demo.py:365-400) ------ */
+
+/* Exact k-nearest neighbours (k <= 32, the point itself excluded) among M points fp32 [M][3], all in one batch, as
+ * torch_cluster.knn_graph(points, k, batch=0, loop=False) in knn_avg_features_pyg (misc.py:61-65).
+ * 1. iggt_knn_morton_codes: 30-bit Morton code of every point on a 1024^3 grid around (cx,cy,cz), cell = 1/inv_cell
+ *    (the grid only orders the points; any centre / cell gives the exact result).  The caller sorts the codes.
+ * 2. iggt_knn_search: order = argsort of the codes (int64 [M]); sorted_ws = 16 * 256 * ceil(M/256) bytes, boxes =
+ *    6 * ceil(M/256) floats of scratch.  idx_out int32 [M][k]: row i = the neighbours of point i, ascending (distance,
+ *    index), -1 where fewer than k other points exist; d2_out (may be NULL) fp32 [M][k] squared distances. */
+int iggt_knn_morton_codes(const float* points, long M, float cx, float cy, float cz, float inv_cell, int* codes,
+                          void* stream);
+int iggt_knn_search(const float* points, const long* order, long M, int k, void* sorted_ws, float* boxes, int* idx_out,
+                    float* d2_out, void* stream);
+
+/* out[i][:] = mean over the valid neighbours j of feat[idx[i][j]][:] (0 when there is none): scatter_mean over the kNN
+ * edges, misc.py:68-71.  feat / out fp32 [M][F]. */
+int iggt_knn_mean_features_f32(const float* feat, const int* idx, long M, int k, int F, float* out, void* stream);
+
+/* First and second moments for the PCA of apply_pca_colormap (misc.py:272-331), C <= 16: every block b writes
+ * iggt_moments_width(C) floats to partials[b]: sum(x - shift) per channel (padded to CT = 4 / 8 / 16), then the upper
+ * triangle of sum((x - shift)(x - shift)^T) row by row over CT channels.  The host adds the partials in fp64. */
+int iggt_moments_f32(const float* x, long M, int C, const float* shift, float* partials, int nblocks, void* stream);
+int iggt_moments_width(int C);
+
+/* out[M][3] = x[M][C] @ v[C][3] (misc.py:299), and the in-place percentile stretch of misc.py:309-326:
+ * channel j -> clamp((v - lohi[j]) / (lohi[3+j] - lohi[j]), 0, 1), or 0.5 where lohi[3+j] <= lohi[j]. */
+int iggt_project3_f32(const float* x, long M, int C, const float* v, float* out, void* stream);
+int iggt_stretch3_f32(float* img, long M, const float* lohi, void* stream);
+
+/* out[i] = ref_labels[argmin_j |query[i] - ref[j]|^2] (first minimum), C <= 16: the nearest-labelled-pixel fill of the
+ * clustering step (NearestNeighbors(n_neighbors=1), misc.py:130-144). */
+int iggt_nn1_label_f32(const float* query, long Mq, const float* ref, long Mr, int C, const int* ref_labels, int* out,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif
