@@ -589,7 +589,7 @@ def count_saturated(x, counter):
 
 
 # ---- post-processing behind the forward path (csrc/postprocess.hip) -----------------------------------------------------
-def _f32c(*ts):
+def _f32_all(*ts):
     for t in ts:
         assert t.dtype == torch.float32 and t.is_contiguous(), "fp32 contiguous tensors expected"
 
@@ -597,7 +597,7 @@ def _f32c(*ts):
 def knn_morton_codes(points, center, inv_cell):
     """points fp32 [M,3] (device) -> int32 [M] Morton codes on a 1024^3 grid around `center` (3 floats), cell 1/inv_cell."""
     _dev(points)
-    _f32c(points)
+    _f32_all(points)
     M = points.shape[0]
     codes = torch.empty(M, dtype=torch.int32, device=points.device)
     rc = load().iggt_knn_morton_codes(points.data_ptr(), M, float(center[0]), float(center[1]), float(center[2]),
@@ -610,7 +610,7 @@ def knn_search(points, order, k, want_dist=False):
     """Exact kNN (self excluded) of points fp32 [M,3] given order = argsort of their Morton codes (int64 [M]).
     -> idx int32 [M,k] (ascending distance, -1 = no such neighbour) and, on request, squared distances fp32 [M,k]."""
     _dev(points, order)
-    _f32c(points)
+    _f32_all(points)
     assert order.dtype == torch.int64 and order.is_contiguous() and order.shape[0] == points.shape[0]
     M = points.shape[0]
     nt = (M + 255) // 256
@@ -627,7 +627,7 @@ def knn_search(points, order, k, want_dist=False):
 def knn_mean_features(feat, idx):
     """feat fp32 [M,F], idx int32 [M,k] -> fp32 [M,F]: mean of the valid neighbours' features (0 where none)."""
     _dev(feat, idx)
-    _f32c(feat)
+    _f32_all(feat)
     assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.shape[0] == feat.shape[0]
     out = torch.empty_like(feat)
     rc = load().iggt_knn_mean_features_f32(feat.data_ptr(), idx.data_ptr(), feat.shape[0], idx.shape[1], feat.shape[1],
@@ -639,7 +639,7 @@ def knn_mean_features(feat, idx):
 def moments(x, shift, nblocks=512):
     """x fp32 [M,C] (C <= 16), shift fp32 [C] -> (sum(x - shift) fp64 [C], sum((x-shift)(x-shift)^T) fp64 [C,C])."""
     _dev(x, shift)
-    _f32c(x, shift)
+    _f32_all(x, shift)
     M, C = x.shape
     width = load().iggt_moments_width(C)
     if width < 0:
@@ -661,7 +661,7 @@ def moments(x, shift, nblocks=512):
 def project3(x, v):
     """x fp32 [M,C] @ v fp32 [C,3] -> fp32 [M,3]."""
     _dev(x, v)
-    _f32c(x, v)
+    _f32_all(x, v)
     assert v.shape == (x.shape[1], 3)
     out = torch.empty(x.shape[0], 3, dtype=torch.float32, device=x.device)
     rc = load().iggt_project3_f32(x.data_ptr(), x.shape[0], x.shape[1], v.data_ptr(), out.data_ptr(), _stream())
@@ -672,7 +672,7 @@ def project3(x, v):
 def stretch3(img, lohi):
     """In place: img fp32 [M,3] channel j -> clamp((v - lohi[j]) / (lohi[3+j] - lohi[j]), 0, 1) (0.5 if degenerate)."""
     _dev(img, lohi)
-    _f32c(img, lohi)
+    _f32_all(img, lohi)
     assert img.shape[1] == 3 and lohi.numel() == 6
     rc = load().iggt_stretch3_f32(img.data_ptr(), img.shape[0], lohi.data_ptr(), _stream())
     _check(rc, "iggt_stretch3_f32")
@@ -682,7 +682,7 @@ def stretch3(img, lohi):
 def nn1_label(query, ref, ref_labels):
     """labels int32 [Mq] of the nearest (first minimum of the squared distance) row of ref fp32 [Mr,C] for every row of query."""
     _dev(query, ref, ref_labels)
-    _f32c(query, ref)
+    _f32_all(query, ref)
     assert ref_labels.dtype == torch.int32 and ref_labels.is_contiguous() and query.shape[1] == ref.shape[1]
     out = torch.empty(query.shape[0], dtype=torch.int32, device=query.device)
     rc = load().iggt_nn1_label_f32(query.data_ptr(), query.shape[0], ref.data_ptr(), ref.shape[0], ref.shape[1],

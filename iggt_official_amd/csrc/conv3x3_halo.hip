@@ -233,6 +233,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     float* stile = reinterpret_cast<float*>(smem);
     constexpr int C4 = BN / 4;
     constexpr int WM_PER_PASS = WAVES_M / 2;
+    // a thread's output segments all have the same 4 channels (512 % C4 == 0): the bias is loaded once.  Loaded per segment
+    // it put an `s_waitcnt vmcnt(0)` -- which also waits for every earlier STORE -- in front of every segment of the layers
+    // without a residual (same finding as gemm_bf16_t256.hip).
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int nb = n0 + (tid % C4) * 4;
+        if (p.bias && nb < p.Cout) bias4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
+    }
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         if (wm / WM_PER_PASS == pass) {
@@ -275,11 +283,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
                 const int row = idx / C4, c4 = idx - row * C4;
                 const int n = n0 + c4 * 4;
                 f32x4 vv = *reinterpret_cast<const f32x4*>(stile + row * BN + c4 * 4);
-                if (p.bias) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) vv[e] += b4[e];
-                }
+                for (int e = 0; e < 4; ++e) vv[e] += bias4[e];
                 if (p.act == 1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) vv[e] = fmaxf(vv[e], 0.f);

@@ -309,6 +309,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
     float* stile = reinterpret_cast<float*>(smem);
     constexpr int EPI_ROWS = T::EPI_ROWS, NPASS = BM / EPI_ROWS;
     constexpr int C4 = BN / 4;
+    // a thread's output segments all have the same 4 channels (THREADS % C4 == 0): the bias is loaded once.  Loaded per
+    // segment it put an `s_waitcnt vmcnt(0)` -- which also waits for every earlier STORE -- in front of every segment of
+    // the layers without a residual (same finding as gemm_bf16_t256.hip).
+    static_assert(THREADS % C4 == 0, "a thread must keep its channel group over the epilogue passes");
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        const int nb = n0 + (tid % C4) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (nb + e < p.Cout) bias4[e] = p.bias[nb + e];
+    }
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
     if (NPASS == 1 || wm == pass) {
@@ -370,10 +381,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
             const long pix = pixs[u];
             f32x4 v = *reinterpret_cast<const f32x4*>(stile + row * BN + c4 * 4);
             const bool full = (n + 3 < p.Cout);  // Cout % 4 != 0 only for the padded 42-channel bottleneck
-            if (p.bias) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (full || n + e < p.Cout) ? p.bias[n + e] : 0.f;
-            }
+            for (int e = 0; e < 4; ++e) v[e] += bias4[e];
             if (p.act == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);

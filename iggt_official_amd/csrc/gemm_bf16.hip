@@ -109,11 +109,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     }
 
     // ---- epilogue ----------------------------------------------------------------------------
+    float bias[2], gamma[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        bias[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+        gamma[j] = (p.gamma && n < p.N) ? p.gamma[n] : 1.f;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + (lane & 31);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) gemm_epilogue_tile<0, FMT>(p, acc[i][j], m0 + wm * 64 + i * 32, n, lane);
+        for (int i = 0; i < 2; ++i)
+            gemm_epilogue_tile<0, FMT>(p, acc[i][j], m0 + wm * 64 + i * 32, n, lane, bias[j], gamma[j]);
     }
 }
 

@@ -188,9 +188,42 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256pp_kernel(const GemmPara
 
     wait_vmcnt<0>();
     __syncthreads();
+    if (DBG & 32) {   // ablation: no epilogue (keeps the accumulators alive through a never-true store)
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+        if (sum == 1.2345e-30f) p.A[0] == p.W[0] ? (void)0 : (void)(*reinterpret_cast<volatile float*>(smem) = sum);
+        return;
+    }
+    // (Measured and dropped for the 16-bit output: the whole tile through LDS as 16-bit in ONE phase -- bias / activation in
+    //  the accumulator layout, ds_write_b16, 16-byte stores: plain 46.3 / GELU 50.2 us per single-round tile vs 44.2 / 50.9 with
+    //  the two fp32 half-tile phases below, and no difference at the full shapes: qkv 746 vs 747, fc1 677 vs 672 TF/s.)
     float* stile = reinterpret_cast<float*>(smem);
+    const int c4 = tid & 63, r0 = tid >> 6;
+    const int n = n0 + c4 * 4;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gamma4 = {1.f, 1.f, 1.f, 1.f};
+    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (MODE == 2 && p.gamma) gamma4 = *reinterpret_cast<const f32x4*>(p.gamma + n);
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
+        // fp32 accumulate (x += gamma * (acc + bias)): a thread's 16 row segments of this half (16 B each, row = 8 * pass +
+        // tid / 64, same 4 columns) are read-modify-write.  ALL 16 old values are requested before the accumulators go through
+        // LDS, so they are in flight during the transposition: as load -> add -> store per pass every load sat behind the
+        // previous, possibly aliasing store (one access in flight per thread: proj 500 TF/s); in two groups of 8 behind the
+        // barrier the second group still waited for the first group's stores (578).
+        f32x4 old[MODE == 2 ? 16 : 1];
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + half * 128 + i * 8 + r0;
+                const int mc = m < p.M ? m : p.M - 1;
+                old[i] = *reinterpret_cast<const f32x4*>(p.out_f32 + (long)mc * p.ldo + n);
+            }
+        }
         if (wm == half) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -201,47 +234,36 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256pp_kernel(const GemmPara
                         stile[(i * 32 + mfma32_row(r, lane)) * TN + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
         }
         __syncthreads();
-        if constexpr (MODE == 2) {
-            // (A 16-byte-store variant of the 16-bit epilogue -- 8 columns per thread, half the store instructions -- measured
-            //  qkv 714 -> 713, fc1 683 -> 645 TF/s and was dropped: the GELU epilogue is VALU-, not store-issue-bound.)
-            // fp32 accumulate (x += gamma * (acc + bias)): a thread's 16 row segments (16 B each, row = 8 * pass + tid / 64,
-            // same 4 columns) are read-modify-write.  The old values of 8 passes are requested up front: written as one
-            // load -> add -> store per pass the compiler has to keep every load behind the previous store (they may alias),
-            // which left ONE 16-byte load in flight per thread.  Measured at M = 43 968: proj 500 -> 578, fc2 800 -> 856 TF/s.
-            const int c4 = tid & 63, r0 = tid >> 6;
-            const int n = n0 + c4 * 4;
-            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gamma4 = {1.f, 1.f, 1.f, 1.f};
-            if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (p.gamma) gamma4 = *reinterpret_cast<const f32x4*>(p.gamma + n);
-#pragma unroll 1
-            for (int pb = 0; pb < 16; pb += 8) {
-                f32x4 old[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int m = m0 + half * 128 + (pb + i) * 8 + r0;
-                    const int mc = m < p.M ? m : p.M - 1;
-                    old[i] = *reinterpret_cast<const f32x4*>(p.out_f32 + (long)mc * p.ldo + n);
-                }
+        for (int pass = 0; pass < 16; ++pass) {
+            const int row = pass * 8 + r0;
+            const int m = m0 + half * 128 + row;
+            f32x4 v4 = *reinterpret_cast<const f32x4*>(stile + row * TN + c4 * 4);
+            if constexpr (MODE == 2) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int row = (pb + i) * 8 + r0;
-                    const int m = m0 + half * 128 + row;
-                    f32x4 v4 = *reinterpret_cast<const f32x4*>(stile + row * TN + c4 * 4);
+                for (int e = 0; e < 4; ++e) v4[e] = fmaf(v4[e] + bias4[e], gamma4[e], old[pass][e]);
+                if (m < p.M) *reinterpret_cast<f32x4*>(p.out_f32 + (long)m * p.ldo + n) = v4;
+            } else if constexpr (MODE == 1) {
+                // the bias is loaded ONCE per thread (its 32 row segments share their 4 columns).  Loaded inside the pass loop
+                // the compiler put `s_waitcnt vmcnt(0)` behind it -- which also waits for every store issued so far: each of
+                // the 32 passes of a tile then cost a memory round trip, 5 of the 12 us this epilogue took (qkv 662 -> 736 TF/s)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v4[e] = fmaf(v4[e] + bias4[e], gamma4[e], old[i][e]);
-                    if (m < p.M) *reinterpret_cast<f32x4*>(p.out_f32 + (long)m * p.ldo + n) = v4;
+                for (int e = 0; e < 4; ++e) v4[e] += bias4[e];
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = gelu_erf(v4[e]);
+                } else if (p.act == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = fmaxf(v4[e], 0.f);
                 }
-            }
-        } else {
-#pragma unroll 4
-            for (int pass = 0; pass < 16; ++pass) {
-                const int idx = pass * 512 + tid;
-                const int row = idx >> 6, c4 = idx & 63;
-                const int m = m0 + half * 128 + row;
-                if (m < p.M) {
-                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(stile + row * TN + c4 * 4);
-                    gemm_epilogue_row4<MODE, FMT>(p, v4, m, n0 + c4 * 4);
-                }
+                u32x2 o;
+                o[0] = pack_h2<FMT>(v4[0], v4[1]);
+                o[1] = pack_h2<FMT>(v4[2], v4[3]);
+                if (m < p.M) *reinterpret_cast<u32x2*>(p.out_bf16 + (long)m * p.ldo + n) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] += bias4[e];
+                if (m < p.M) gemm_epilogue_row4_nobias<MODE, FMT>(p, v4, m, n);
             }
         }
         __syncthreads();
@@ -266,7 +288,8 @@ static int launch_t256(const GemmParams& p, int mode, int tiles_m, hipStream_t s
             (const void*)gemm_bf16_t256pp_kernel<1, 16, FMT>, (const void*)gemm_bf16_t256pp_kernel<2, 16, FMT>,
             (const void*)gemm_bf16_t256pp_kernel<3, 16, FMT>, (const void*)gemm_bf16_t256pp_kernel<2, 0, FMT>,
             (const void*)gemm_bf16_t256pp_kernel<2, 8, FMT>,  (const void*)gemm_bf16_t256pp_kernel<2, 17, FMT>,
-            (const void*)gemm_bf16_t256pp_kernel<2, 20, FMT>};
+            (const void*)gemm_bf16_t256pp_kernel<2, 20, FMT>, (const void*)gemm_bf16_t256pp_kernel<1, 48, FMT>,
+            (const void*)gemm_bf16_t256pp_kernel<2, 48, FMT>};
         for (const void* k : kernels) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return (int)e;
@@ -274,6 +297,11 @@ static int launch_t256(const GemmParams& p, int mode, int tiles_m, hipStream_t s
         attr_set = true;
     }
     const dim3 grid(tiles_m * p.tiles_n), block(512);
+    if (ppdbg == 32 && mode != 3) {
+        if (mode == 1) hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<1, 48, FMT>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<2, 48, FMT>), grid, block, lds, stream, p);
+        return 0;
+    }
     if (ppdbg >= 0 && mode == 2) {
         if (ppdbg == 1) hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<2, 17, FMT>), grid, block, lds, stream, p);
         else if (ppdbg == 4) hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<2, 20, FMT>), grid, block, lds, stream, p);

@@ -42,10 +42,11 @@ IGGT_DEVINL float gelu_erf(float x) {
 // allocation of the big-tile kernel) small:  1 = bf16 out, bias + act;  2 = fp32 accumulate, bias + gamma;
 // 3 = fp32 store, bias (+ row remap / additive table).
 template <int MODE, int FMT>
-IGGT_DEVINL void gemm_epilogue_tile(const GemmParams& p, const f32x16& acc, int m_base, int n, int lane) {
+IGGT_DEVINL void gemm_epilogue_tile(const GemmParams& p, const f32x16& acc, int m_base, int n, int lane, float bias,
+                                    float gamma) {
+    // bias / gamma of column n come from the caller, loaded once per column BEFORE the first store of the tile: a load placed
+    // between the fragments' stores makes the compiler wait for every store issued so far (vmcnt counts both)
     if (n >= p.N) return;
-    const float bias = p.bias ? p.bias[n] : 0.f;
-    const float gamma = (MODE == 0 || MODE == 2) ? (p.gamma ? p.gamma[n] : 1.f) : 1.f;
     if (MODE == 0 && p.out_f32 && p.accumulate && p.rows_in == 0 && p.act == 0) {
         // residual accumulate: request the 16 old values before the first store -- as load / add / store per element every
         // load has to wait behind the previous (possibly aliasing) store and the epilogue runs at one access in flight
@@ -97,50 +98,20 @@ IGGT_DEVINL void gemm_epilogue_tile(const GemmParams& p, const f32x16& acc, int 
     }
 }
 
-// Same epilogue on 4 consecutive columns n..n+3 of row m (vector loads/stores; N % 4 == 0, n + 3 < N).
+// MODE 3 (fp32 store, optional row remap + additive table) with the bias already added by the caller
 template <int MODE, int FMT>
-IGGT_DEVINL void gemm_epilogue_row4(const GemmParams& p, f32x4 v, int m, int n) {
-    if (p.bias) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+IGGT_DEVINL void gemm_epilogue_row4_nobias(const GemmParams& p, f32x4 v, int m, int n) {
+    long orow = m;
+    if (p.rows_in > 0) {
+        const int g = m / p.rows_in, w = m - g * p.rows_in;
+        orow = (long)g * p.rows_out + p.row_off + w;
+        if (p.add_table) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p.add_table + (long)w * p.N + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += b[e];
+            for (int e = 0; e < 4; ++e) v[e] += t[e];
+        }
     }
-    if (MODE == 1) {
-        if (p.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-        } else if (p.act == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        u32x2 o;
-        o[0] = pack_h2<FMT>(v[0], v[1]);
-        o[1] = pack_h2<FMT>(v[2], v[3]);
-        *reinterpret_cast<u32x2*>(p.out_bf16 + (long)m * p.ldo + n) = o;
-    } else if (MODE == 2) {
-        if (p.gamma) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= g[e];
-        }
-        f32x4* dst = reinterpret_cast<f32x4*>(p.out_f32 + (long)m * p.ldo + n);
-        const f32x4 old = *dst;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += old[e];
-        *dst = v;
-    } else {
-        long orow = m;
-        if (p.rows_in > 0) {
-            const int g = m / p.rows_in, w = m - g * p.rows_in;
-            orow = (long)g * p.rows_out + p.row_off + w;
-            if (p.add_table) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(p.add_table + (long)w * p.N + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += t[e];
-            }
-        }
-        *reinterpret_cast<f32x4*>(p.out_f32 + orow * p.ldo + n) = v;
-    }
+    *reinterpret_cast<f32x4*>(p.out_f32 + orow * p.ldo + n) = v;
 }
 
 // returns -100 when the parameter combination has no specialised big-tile kernel (caller falls back)
