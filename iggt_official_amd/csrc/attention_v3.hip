@@ -20,6 +20,12 @@
 // interleave: 809 vs 935 TF/s, fp16); a mixed-tile launch that hands the last, 37 %-full round of 256-row tiles to
 // 128-row tiles (correct, but 1.5 % slower: a CU left with ONE resident workgroup already runs it ~1.7x faster, so
 // the partial round costs ~0.6 of a full one, not 1.0).
+// Round 2, static-bound kernel: row sums on the matrix pipe again, this time almost free -- a packed P fragment read as the
+// B operand of a 16x16x32 MFMA against a 0/1 selector A (row 0 = ones on k-groups {0, 2}, row 1 = on {1, 3}) adds its 16 keys
+// to D[0][n] = l(query n), D[1][n] = l(query n + 16): 4 four-pass MFMAs per 64-key tile instead of 36 v_add, a third of the
+// VALU instructions gone, results identical -- and 7.02 vs 7.09 ms (fp16), 6.75 vs 6.68 ms (bf16): the loop is not bound by VALU
+// throughput (VALU pipe 74 % busy, matrix pipe 60 %) but by the in-order issue of each wave.  128-row tiles at three
+// waves per SIMD instead of the staggered pair: 1 000 vs 1 100 TF/s (probes/attn_tile_codes.py).
 // Ablation: the same kernel without any softmax VALU work reaches 1 210 TF/s -- the d = 64 softmax (64 exp +
 // ~140 other VALU ops per 32 MFMA) is what separates this kernel from the matrix-pipe limit.
 //
