@@ -42,6 +42,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
+# What the matrix pipe sustains from registers alone once the operands are real data (the chip is power-limited: 2.38 GHz
+# with zero / constant operands, 1.51 GHz fp16 / 1.64 GHz bf16 with random ones) -- probes/mfma_power.hip,
+# profiles/r02_mfma_power.txt.  Reported beside the contract's peak, never instead of it.
+MFMA_SUSTAINED_REAL_DATA_TFLOPS = {"f16": 1581.0, "bf16": 1721.0}
 # HBM-side bytes per global-attention launch, from rocprofv3 PMC passes on the kernel named in the entry
 # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes; MI355X_MICROARCH.md section HBM).  PMC counters cannot
 # be read live inside the timed run, so the figure is keyed by (views, size, n_gpus, kernel label) and reported as
@@ -299,6 +303,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kernel_label + " (global attention)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+                         "sustained_mfma_rate_on_random_operands": MFMA_SUSTAINED_REAL_DATA_TFLOPS.get(precision.operand_name()),
+                         "frac_of_sustained": achieved / MFMA_SUSTAINED_REAL_DATA_TFLOPS.get(precision.operand_name(),
+                                                                                             MFMA_BF16_PEAK_TFLOPS),
+                         "sustained_note": "register-only MFMA loop, random operands: the chip's power limit for real data "
+                                           "(profiles/r02_mfma_power.txt); 'peak' is reached with zero operands only",
                          "traffic": traffic.get("bytes_per_launch"),
                          "traffic_note": traffic.get("note", "no rocprofv3 PMC pass recorded for this kernel / shape "
                                                              "(profiles/attn_traffic.json)"),

@@ -26,6 +26,11 @@
 // VALU instructions gone, results identical -- and 7.02 vs 7.09 ms (fp16), 6.75 vs 6.68 ms (bf16): the loop is not bound by VALU
 // throughput (VALU pipe 74 % busy, matrix pipe 60 %) but by the in-order issue of each wave.  128-row tiles at three
 // waves per SIMD instead of the staggered pair: 1 000 vs 1 100 TF/s (probes/attn_tile_codes.py).
+// Also measured (probes/legacy/attention_r2_v5_tile_pipelined.hip): the four MFMA groups re-ordered across tiles so that EVERY
+// group has half an exp/pack unit beside it (QK^T(q0, t+1) before PV(q1, t); 238 VGPRs, no spill): 7.68 vs 7.28 ms; both query
+// blocks sharing every K / V fragment (half the LDS reads, no intra-wave overlap): 7.70 ms.  Three instruction orders within
+// 5 %, bf16 operands 7 % faster than fp16 on the identical instruction stream, effective clock 1.77 GHz: the kernel runs at
+// the chip's power limit for 16-bit MFMA on real data.
 // Ablation: the same kernel without any softmax VALU work reaches 1 210 TF/s -- the d = 64 softmax (64 exp +
 // ~140 other VALU ops per 32 MFMA) is what separates this kernel from the matrix-pipe limit.
 //
