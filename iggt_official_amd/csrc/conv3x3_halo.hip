@@ -37,13 +37,20 @@ struct HaloParams {
     int tiles_x, tiles_y, tiles_n;
 };
 
-constexpr int TH = 8, TW = 32;
-constexpr int HH = TH + 2, HW = TW + 2;
-constexpr int HALO_PX = HH * HW;               // 340
-constexpr int HALO_PLANE = HALO_PX * 64;       // one bf16 plane of a 32-channel slice
-constexpr int HALO_BYTES = 2 * HALO_PLANE;     // hi + lo
-constexpr int HALO_ITEMS = HALO_PX * 8;        // float4 groups per slice
-constexpr int HALO_ITERS = (HALO_ITEMS + 511) / 512;   // 6
+// Tile shape: 256 output pixels as 8 x 32 (halo 10 x 34 = 340 pixels) or 16 x 16 (halo 18 x 18 = 324).  An MFMA row block
+// is 32 consecutive pixels of the tile in row-major order: one tile row of the wide tile, two rows of the square one.  The
+// launcher picks the shape that pads the map less (74 x 74: 30 wide tiles = 1.40 x the map, 25 square ones = 1.17 x).
+template <int TWD>
+struct TileShape {
+    static constexpr int TW = TWD, TH = 256 / TWD;
+    static constexpr int RPB = 32 / TWD;               // tile rows per MFMA row block
+    static constexpr int HH = TH + 2, HW = TW + 2;
+    static constexpr int HALO_PX = HH * HW;
+    static constexpr int HALO_PLANE = HALO_PX * 64;    // one bf16 plane of a 32-channel slice
+    static constexpr int HALO_BYTES = 2 * HALO_PLANE;  // hi + lo
+    static constexpr int HALO_ITEMS = HALO_PX * 8;     // float4 groups per slice
+    static constexpr int HALO_ITERS = (HALO_ITEMS + 511) / 512;   // 6
+};
 constexpr int NWBUF = 3;
 
 typedef __attribute__((address_space(1))) const void gptr_t;
@@ -54,19 +61,23 @@ IGGT_DEVINL void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN>
+template <int BN, int TWD>
 struct HaloTile {
-    static constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N, MI = TH / WAVES_M;
+    using S = TileShape<TWD>;
+    static constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N, MI = 8 / WAVES_M;   // 8 row blocks of 32 pixels
     static constexpr int W_STAGE = 2 * BN * 64;                     // hi + lo rows of one (tap, slice)
     static constexpr int NI = W_STAGE / (512 * 16);                 // DMA instructions per thread and step
     static constexpr int EPI_BYTES = 128 * BN * 4;                  // 128 pixels per epilogue pass
-    static constexpr int MAIN_BYTES = HALO_BYTES + NWBUF * W_STAGE;
+    static constexpr int MAIN_BYTES = S::HALO_BYTES + NWBUF * W_STAGE;
     static constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
 };
 
-template <int BN>
+template <int BN, int TWD>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p) {
-    using T = HaloTile<BN>;
+    using T = HaloTile<BN, TWD>;
+    using S = TileShape<TWD>;
+    constexpr int TH = S::TH, TW = S::TW, HW = S::HW, RPB = S::RPB, HALO_PLANE = S::HALO_PLANE, HALO_BYTES = S::HALO_BYTES,
+                  HALO_ITEMS = S::HALO_ITEMS, HALO_ITERS = S::HALO_ITERS;
     constexpr int WAVES_N = T::WAVES_N, WAVES_M = T::WAVES_M, MI = T::MI, W_STAGE = T::W_STAGE, NI = T::NI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
@@ -165,7 +176,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) boff[j][kc] = n * 64 + ((((2 * kc + fhalf) ^ (n >> 2)) & 3) << 4);
     }
-    const int q_base = (wm * MI) * HW + frow;   // halo pixel of (tile row wm * MI, column frow) for tap (0, 0)
+    // halo pixel of this lane's pixel of row block wm * MI for tap (0, 0): tile row (wm * MI) * RPB + frow / TW, column frow % TW
+    const int q_base = ((wm * MI) * RPB + frow / TW) * HW + (frow % TW);
 
     auto compute = [&](int s) {
         const int t = s % 9;
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
             bf16x8 ah[MI], al[MI], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const int q = q0 + i * HW;
+                const int q = q0 + i * RPB * HW;
                 const int off = q * 64 + ((((2 * kc + fhalf) ^ (q >> 2)) & 3) << 4);
                 ah[i] = *reinterpret_cast<const bf16x8*>(halo + off);
                 al[i] = *reinterpret_cast<const bf16x8*>(halo + HALO_PLANE + off);
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
                 const int idx = idx0 + u * 512;
                 const int row = idx / C4, c4 = idx - row * C4;
                 const int m = pass * 128 + row;
-                const int oy = oy0 + (m >> 5), ox = ox0 + (m & 31);
+                const int oy = oy0 + m / TW, ox = ox0 + m % TW;   // the 256 pixels of a tile are numbered row-major
                 const int n = n0 + c4 * 4;
                 ok[u] = idx < 128 * C4 && oy < p.H && ox < p.W && n < p.Cout;
                 pixs[u] = ok[u] ? ((long)img * p.H + oy) * p.W + ox : 0;
@@ -306,12 +318,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     }
 }
 
-template <int BN>
+template <int BN, int TWD>
 int launch_halo(const HaloParams& p_in, hipStream_t st) {
-    using T = HaloTile<BN>;
+    using T = HaloTile<BN, TWD>;
+    constexpr int TW = TWD, TH = 256 / TWD;
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN>,
+        const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, TWD>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -321,7 +334,7 @@ int launch_halo(const HaloParams& p_in, hipStream_t st) {
     p.tiles_y = (p.H + TH - 1) / TH;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const long grid = (long)p.Nimg * p.tiles_y * p.tiles_x * p.tiles_n;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BN>), dim3((unsigned)grid), dim3(512), T::SMEM, st, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TWD>), dim3((unsigned)grid), dim3(512), T::SMEM, st, p);
     return 0;
 }
 
@@ -346,5 +359,14 @@ int iggt_launch_conv3x3_halo(const float* x, int ldx, const void* w_hi, const vo
     p.Nimg = Nimg; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldy = ldy; p.ldr = ldr;
     p.relu_in = relu_in; p.relu_res = relu_res; p.act = act;
     p.tiles_x = p.tiles_y = p.tiles_n = 0;
-    return (Cout % 256) == 0 ? launch_halo<256>(p, st) : launch_halo<128>(p, st);
+    // tile shape by padded area (ties -> the wide tile); IGGT_CONV_HALO_TILE=8x32 | 16x16 forces one (A/B runs)
+    static int force = -1;
+    if (force < 0) {
+        const char* e = getenv("IGGT_CONV_HALO_TILE");
+        force = (e && e[0] == '8') ? 32 : ((e && e[0] == '1') ? 16 : 0);
+    }
+    const long wide = (long)((H + 7) / 8) * ((W + 31) / 32), square = (long)((H + 15) / 16) * ((W + 15) / 16);
+    const bool sq = force ? force == 16 : square < wide;
+    if ((Cout % 256) == 0) return sq ? launch_halo<256, 16>(p, st) : launch_halo<256, 32>(p, st);
+    return sq ? launch_halo<128, 16>(p, st) : launch_halo<128, 32>(p, st);
 }

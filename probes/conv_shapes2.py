@@ -25,7 +25,7 @@ def worker():
         return sorted(ts)[len(ts) // 2]
 
     for views, hw, cin, cout in ((32, 148, 256, 256), (32, 296, 256, 128), (32, 74, 256, 256), (32, 74, 512, 256), (8, 144, 256, 256),
-                                 (8, 288, 256, 128), (4, 148, 256, 256)):
+                                 (8, 288, 256, 128), (8, 72, 256, 256), (4, 148, 256, 256)):
         conv = nn.Conv2d(cin, cout, 3, 1, 1).cuda()
         pc = co.pack_conv2d(conv)
         x = torch.randn(views, hw, hw, cin, device="cuda")
@@ -40,6 +40,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         worker()
     else:
-        for halo in ("1", "0"):
-            print(f"== IGGT_CONV_HALO={halo}", flush=True)
-            subprocess.run([sys.executable, os.path.abspath(__file__), "w"], env=dict(os.environ, IGGT_CONV_HALO=halo))
+        for halo, tile in (("1", ""), ("1", "8x32"), ("1", "16x16"), ("0", "")):
+            print(f"== IGGT_CONV_HALO={halo} IGGT_CONV_HALO_TILE={tile or 'auto'}", flush=True)
+            env = dict(os.environ, IGGT_CONV_HALO=halo)
+            if tile:
+                env["IGGT_CONV_HALO_TILE"] = tile
+            subprocess.run([sys.executable, os.path.abspath(__file__), "w"], env=env)
