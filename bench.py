@@ -242,7 +242,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1 if graphs else 0)):
+    graph_note = None
+    if graphs:
+        # the first call captures.  If capture fails (deterministically, so on every rank at the same point) fall back to
+        # eager launches rather than lose the measurement; the JSON line says which mode was timed.
+        try:
+            step()
+            fence()
+        except Exception as ex:  # noqa: BLE001
+            graph_note = f"hipGraph capture failed, timed eager launches instead: {ex!r}"[:300]
+            graphs = False
+            model.enable_graphs(False)
+            torch.cuda.synchronize()
+    for _ in range(max(args.warmup - (1 if graphs else 0), 0)):
         step()
     fence()
     if not graphs:
@@ -297,6 +309,7 @@ def main():
             "dtype": precision.operand_name(),
             "data": data,
             "graphs": bool(graphs),
+            **({"graphs_note": graph_note} if graph_note else {}),
             "config": {"workload": f"{S} views @ {H}x{H}, IGGT forward (DINOv2 + 24x(frame,global) + camera/depth/"
                                    "point heads), synthetic weights, views sharded " + f"{S // world}/GPU",
                        "views": S, "image_size": H, "tokens_per_view": P, "parallelism": f"view-shard x{world}"},
