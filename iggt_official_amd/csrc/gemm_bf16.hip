@@ -125,6 +125,200 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Same 128 x 128 tile, operands staged by LDS-DMA through a 4-deep ring of 32-wide K stages (4 x 16 KiB = 64 KiB, still two
+// workgroups per CU) instead of global -> register -> ds_write one K tile ahead.  The register-staged loop above keeps ONE
+// 64-wide K tile in flight per workgroup: a K step (16 MFMAs per wave, ~0.3 us of matrix pipe) cannot cover a global-load
+// latency of 1-2 us, and the kernel ran latency-bound at 245-476 TF/s on the shapes it gets in a sharded run (per-rank
+// proj / fc2: M = 5 496, N = 1 024).  Here up to three stages are in flight behind counted vmcnt waits, one barrier per
+// stage (all four waves in lockstep -- the second workgroup of the CU fills the read phases).  LDS image and source-side
+// swizzle as in gemm_bf16_t256.hip: 64-byte rows, chunk j of 1 KiB = rows 16j .. 16j + 15, lane l -> row 16j + l / 4,
+// slot l % 4 filled with source piece (l % 4) ^ ((row >> 2) & 3).
+constexpr int DK = 32, DSTAGES = 4;
+constexpr int D_OP_BYTES = BM * DK * 2;        // 8 KiB per operand per stage
+constexpr int D_STAGE_BYTES = 2 * D_OP_BYTES;  // A + W
+
+template <int N>
+IGGT_DEVINL void wait_vmcnt_n() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// EPI_LDS: the accumulators leave through LDS (the idle ring: 128 x 128 fp32 = 64 KiB) as 16-byte row segments -- the direct
+// epilogue issues 64 scalar loads + 64 scalar 4-byte (or 2-byte) stores per lane, which was most of the 41 us a K = 1 024
+// tile took.  Needs N % 4 == 0, ldo % 4 == 0 and a 16-byte aligned output (launcher).
+template <int FMT, bool EPI_LDS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = v / p.tiles_n, tn = v - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // wave w moves chunks 2w, 2w + 1 of A and of W (rows 32w .. 32w + 31 of each operand)
+    const int c_row = lane >> 2, c_pos = lane & 3;
+    int a_off[2], w_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (2 * wave + i) * 16 + c_row;
+        const int piece = c_pos ^ ((r >> 2) & 3);
+        int ra = m0 + r;
+        ra = ra < p.M ? ra : p.M - 1;   // tail rows: duplicate the last row, masked at the store
+        int rw = n0 + r;
+        rw = rw < p.N ? rw : p.N - 1;
+        a_off[i] = ra * (int)p.lda + piece * 8;
+        w_off[i] = rw * (int)p.ldw + piece * 8;
+    }
+    auto dma = [&](int kt) {
+        char* st = smem + (kt & (DSTAGES - 1)) * D_STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t*)(p.A + a_off[i] + kt * DK), (lptr_t*)(st + (2 * wave + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t*)(p.W + w_off[i] + kt * DK),
+                                             (lptr_t*)(st + D_OP_BYTES + (2 * wave + i) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int lane_off[2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) lane_off[kc] = frow * 64 + ((((2 * kc + fhalf) ^ (frow >> 2)) & 3) << 4);
+    const int a_base = wm * 64 * 64, w_base = D_OP_BYTES + wn * 64 * 64;
+    const int KT = p.K / DK;
+
+    dma(0);
+    if (KT > 1) dma(1);
+    if (KT > 2) dma(2);
+#pragma unroll 1
+    for (int s = 0; s < KT; ++s) {
+        // stage s has landed: at most the stages s + 1, s + 2 (4 DMA instructions each) may still be in flight
+        if (s + 2 < KT) wait_vmcnt_n<8>();
+        else if (s + 1 < KT) wait_vmcnt_n<4>();
+        else wait_vmcnt_n<0>();
+        __builtin_amdgcn_s_barrier();          // ... in every wave, and every wave is done with stage s - 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 3 < KT) dma(s + 3);            // into the slot of stage s - 1
+        const char* st = smem + (s & (DSTAGES - 1)) * D_STAGE_BYTES;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 32 * 64 + lane_off[kc]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(st + w_base + j * 32 * 64 + lane_off[kc]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32h<FMT>(a[i], b[j], acc[i][j]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of stage s are complete
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if constexpr (EPI_LDS) {
+        __syncthreads();   // every wave is done with the ring
+        float* stile = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stile[(wm * 64 + i * 32 + mfma32_row(r, lane)) * BN + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+        // a thread's 16 row segments (row = 8 * pass + tid / 32) share their 4 columns: bias / gamma once, and in the
+        // accumulate mode all 16 old values are requested before the first store (a load behind a store waits for it)
+        const int c4 = tid & 31, r0 = tid >> 5;
+        const int n = n0 + c4 * 4;
+        const bool ncol = n < p.N;
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gamma4 = {1.f, 1.f, 1.f, 1.f};
+        if (ncol && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (ncol && p.gamma) gamma4 = *reinterpret_cast<const f32x4*>(p.gamma + n);
+        const bool rmw = p.out_f32 && p.accumulate && p.rows_in == 0;
+        f32x4 old[16];
+        if (rmw) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + i * 8 + r0;
+                const int mc = m < p.M ? m : p.M - 1;
+                old[i] = ncol ? *reinterpret_cast<const f32x4*>(p.out_f32 + (long)mc * p.ldo + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 16; ++pass) {
+            const int row = pass * 8 + r0;
+            const int m = m0 + row;
+            if (m >= p.M || !ncol) continue;
+            f32x4 v4 = *reinterpret_cast<const f32x4*>(stile + row * BN + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] += bias4[e];
+            if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = gelu_erf(v4[e]);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = fmaxf(v4[e], 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] *= gamma4[e];
+            long orow = m;
+            if (p.rows_in > 0) {
+                const int g = m / p.rows_in, w = m - g * p.rows_in;
+                orow = (long)g * p.rows_out + p.row_off + w;
+                if (p.add_table) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(p.add_table + (long)w * p.N + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] += t[e];
+                }
+            }
+            if (p.out_f32) {
+                float* dst = p.out_f32 + orow * p.ldo + n;
+                if (rmw) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] += old[pass][e];
+                } else if (p.accumulate) {
+                    const f32x4 o4 = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] += o4[e];
+                }
+                *reinterpret_cast<f32x4*>(dst) = v4;
+            } else {
+                u32x2 o;
+                o[0] = pack_h2<FMT>(v4[0], v4[1]);
+                o[1] = pack_h2<FMT>(v4[2], v4[3]);
+                *reinterpret_cast<u32x2*>(p.out_bf16 + orow * p.ldo + n) = o;
+            }
+        }
+        return;
+    }
+
+    float bias[2], gamma[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        bias[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+        gamma[j] = (p.gamma && n < p.N) ? p.gamma[n] : 1.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            gemm_epilogue_tile<0, FMT>(p, acc[i][j], m0 + wm * 64 + i * 32, n, lane, bias[j], gamma[j]);
+    }
+}
+
 }  // namespace
 
 static int force_small_tile() {
@@ -179,6 +373,41 @@ static int gemm_h16(int fmt, const void* A, long lda, const void* W, long ldw, i
         attr_set = true;
     }
     const dim3 grid(tiles_m * p.tiles_n), block(256);
+    // LDS-DMA variant: needs 32-bit operand offsets and 16-byte aligned, 8-element-strided operand rows (checked above);
+    // IGGT_GEMM128_DMA=0 selects the register-staged loop (A/B runs)
+    static int dma_on = -1;
+    if (dma_on < 0) {
+        const char* e = getenv("IGGT_GEMM128_DMA");
+        dma_on = (e && e[0] == '0') ? 0 : 1;
+    }
+    const bool small_offsets = (long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31);
+    const bool aligned = (((uintptr_t)A | (uintptr_t)W) % 16) == 0;
+    if (dma_on && small_offsets && aligned) {
+        constexpr int DLDS = DSTAGES * D_STAGE_BYTES;
+        static bool attr_dma = false;
+        if (!attr_dma) {
+            const void* ks[] = {(const void*)gemm_bf16_dma_kernel<FMT_BF16, false>, (const void*)gemm_bf16_dma_kernel<FMT_F16, false>,
+                                (const void*)gemm_bf16_dma_kernel<FMT_BF16, true>, (const void*)gemm_bf16_dma_kernel<FMT_F16, true>};
+            for (const void* k : ks) {
+                const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+                if (e != hipSuccess) return (int)e;
+            }
+            attr_dma = true;
+        }
+        const bool epi_lds = (N % 4) == 0 && (ldo % 4) == 0 && ((uintptr_t)out % 16) == 0 &&
+                             (!bias || ((uintptr_t)bias % 16) == 0) && (!gamma || ((uintptr_t)gamma % 16) == 0) &&
+                             (!add_table || ((uintptr_t)add_table % 16) == 0);
+        hipStream_t st = (hipStream_t)stream;
+        if (epi_lds) {
+            if (fmt == FMT_F16) hipLaunchKernelGGL((gemm_bf16_dma_kernel<FMT_F16, true>), grid, block, DLDS, st, p);
+            else hipLaunchKernelGGL((gemm_bf16_dma_kernel<FMT_BF16, true>), grid, block, DLDS, st, p);
+        } else {
+            if (fmt == FMT_F16) hipLaunchKernelGGL((gemm_bf16_dma_kernel<FMT_F16, false>), grid, block, DLDS, st, p);
+            else hipLaunchKernelGGL((gemm_bf16_dma_kernel<FMT_BF16, false>), grid, block, DLDS, st, p);
+        }
+        IGGT_CHECK_LAUNCH();
+        return 0;
+    }
     if (fmt == FMT_F16) hipLaunchKernelGGL(gemm_bf16_kernel<FMT_F16>, grid, block, lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_bf16_kernel<FMT_BF16>, grid, block, lds, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
