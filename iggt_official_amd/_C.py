@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -79,6 +79,9 @@ _SIGNATURES = {
     "iggt_bilinear_ac_nhwc_f32": [_c_void_p, _c_int, _c_void_p, _c_int] + [_c_int] * 6 + [_c_void_p] * 3,
     "iggt_linear_f32": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p,
                         _c_long, _c_int, _c_int, _c_int, _c_int, _c_void_p],
+    "iggt_linear_f32_ws": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p,
+                           _c_long, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_long, _c_void_p],
+    "iggt_linear_f32_ws_bytes": [],
     "iggt_attn_f32": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                       _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_float, _c_void_p],
     "iggt_adaln_modulate_f32": [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_long,
@@ -105,7 +108,7 @@ _SIGNATURES = {
 }
 
 
-_LONG_RETURN = {"iggt_flash_attn_static_ws_bytes"}
+_LONG_RETURN = {"iggt_flash_attn_static_ws_bytes", "iggt_linear_f32_ws_bytes"}
 
 
 class HipExtensionError(RuntimeError):
@@ -473,11 +476,27 @@ def linear_f32(x, weight, bias=None, *, act=None, gamma=None, res=None, out=None
     assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
     if res is not None:
         assert res.dtype == torch.float32 and res.shape == (M, N) and res.stride(1) == 1
-    rc = load().iggt_linear_f32(x.data_ptr(), x.stride(0), weight.data_ptr(), K, _ptr(_f32c(bias, "bias")),
-                                _ptr(_f32c(gamma, "gamma")), _ptr(res), 0 if res is None else res.stride(0),
-                                out.data_ptr(), out.stride(0), M, N, K, LIN_ACT[act], _stream())
-    _check(rc, "iggt_linear_f32")
+    ws = _linear_ws(x.device)
+    if os.environ.get("IGGT_LINEAR_SPLITK", "1") == "0":    # A/B runs: one workgroup per output tile
+        ws = torch.empty(0, dtype=torch.uint8, device=x.device)
+    rc = load().iggt_linear_f32_ws(x.data_ptr(), x.stride(0), weight.data_ptr(), K, _ptr(_f32c(bias, "bias")),
+                                   _ptr(_f32c(gamma, "gamma")), _ptr(res), 0 if res is None else res.stride(0),
+                                   out.data_ptr(), out.stride(0), M, N, K, LIN_ACT[act], ws.data_ptr() if ws.numel() else 0, ws.numel(),
+                                   _stream())
+    _check(rc, "iggt_linear_f32_ws")
     return out
+
+
+_LINEAR_WS = {}
+
+
+def _linear_ws(device):
+    """Split-K scratch of iggt_linear_f32_ws: one zero-filled buffer per device, shared by all launches (they are ordered
+    on one stream); allocated on first use, i.e. in the eager warm-up that precedes any hipGraph capture."""
+    ws = _LINEAR_WS.get(device)
+    if ws is None:
+        ws = _LINEAR_WS[device] = torch.zeros(load().iggt_linear_f32_ws_bytes(), dtype=torch.uint8, device=device)
+    return ws
 
 
 def attn_f32(q, k, v, o, B, H, Nq, Nk, head_dim, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale):

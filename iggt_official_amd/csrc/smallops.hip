@@ -30,6 +30,12 @@ struct LinParams {
     const float* res; long ldr;
     float* out; long ldo;
     int M, N, K, act;
+    // split-K over blockIdx.z (ks > 1): the ks workgroups of a tile write their partial 32 x 32 sums to part[tile][z][1024];
+    // a second, tiny kernel adds them in z order (fixed summation order) and applies the epilogue.  (One kernel with a
+    // "last workgroup to arrive reduces" counter was 10x SLOWER than no split at all: the device-scope release it needs
+    // writes back the L2 of the XCD, and the 8 XCDs of this chip do not share an L2.)
+    int ks, kchunks;          // K chunks of 16 per z slice
+    float* part;
 };
 
 IGGT_DEVINL float lin_act(float v, int act) {
@@ -58,8 +64,11 @@ __global__ __launch_bounds__(512) void linear_f32_kernel(const LinParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     // k chunks of 16 interleaved over the 8 waves: lane half h owns k = 16 c + 8 h + [0, 8)
-    const int nchunks = (p.K + 15) >> 4;
-    for (int c = wave; c < nchunks; c += 8) {
+    const int nchunks_all = (p.K + 15) >> 4;
+    const int cbeg = blockIdx.z * p.kchunks;
+    const int nchunks = (cbeg + p.kchunks < nchunks_all) ? cbeg + p.kchunks : nchunks_all;
+#pragma unroll 4
+    for (int c = cbeg + wave; c < nchunks; c += 8) {
         const int k0 = c * 16 + 8 * h;
         float xa[8], wb[8];
         if (ALIGNED && c * 16 + 16 <= p.K) {
@@ -81,12 +90,26 @@ __global__ __launch_bounds__(512) void linear_f32_kernel(const LinParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) red[wave][mfma32_row(i, lane)][r] = acc[i];
     __syncthreads();
+    float vsum[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int idx = e * 512 + tid, row = idx >> 5, col = idx & 31;
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) v += red[w][row][col];
+        vsum[e] = v;
+    }
+    if (p.ks > 1) {   // split K: this workgroup's partial sums; linear_finalize_kernel adds the slices and applies the epilogue
+        const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+        float* mine = p.part + ((long)tile * p.ks + blockIdx.z) * 1024;
+        mine[tid] = vsum[0];
+        mine[512 + tid] = vsum[1];
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int idx = e * 512 + tid, row = idx >> 5, col = idx & 31;
+        float v = vsum[e];
         const int m = m0 + row, n = n0 + col;
         if (m < p.M && n < p.N) {
             if (p.bias) v += p.bias[n];
@@ -96,6 +119,22 @@ __global__ __launch_bounds__(512) void linear_f32_kernel(const LinParams p) {
             p.out[(long)m * p.ldo + n] = v;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void linear_finalize_kernel(const LinParams p, int tiles_n) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // element (m, n) of the padded [tiles_m * 32][tiles_n * 32] grid
+    const int ncols = tiles_n * 32;
+    const int m = idx / ncols, n = idx - m * ncols;
+    if (m >= p.M || n >= p.N) return;
+    const int tile = (m >> 5) * tiles_n + (n >> 5);
+    const float* src = p.part + (long)tile * p.ks * 1024 + (m & 31) * 32 + (n & 31);
+    float v = 0.f;
+    for (int z = 0; z < p.ks; ++z) v += src[z * 1024];
+    if (p.bias) v += p.bias[n];
+    v = lin_act(v, p.act);
+    if (p.gamma) v *= p.gamma[n];
+    if (p.res) v += p.res[(long)m * p.ldr + n];
+    p.out[(long)m * p.ldo + n] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -302,19 +341,51 @@ __global__ __launch_bounds__(256) void unproject_depth_kernel(const float* depth
 
 }  // namespace
 
-extern "C" int iggt_linear_f32(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* gamma,
-                               const float* res, long ldr, float* out, long ldo, int M, int N, int K, int act,
-                               void* stream) {
+static const long LIN_WS_COUNTERS = 4096;   // ints in front of the partial sums
+
+extern "C" int iggt_linear_f32_ws(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* gamma,
+                                  const float* res, long ldr, float* out, long ldo, int M, int N, int K, int act,
+                                  void* ws, long ws_bytes, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 4) return -1;
     if (ldx < K || ldw < K || ldo < N || (res && ldr < N)) return -2;
-    LinParams p{x, ldx, w, ldw, bias, gamma, res, ldr, out, ldo, M, N, K, act};
-    const dim3 grid((N + 31) / 32, (M + 31) / 32), block(512);
+    LinParams p{x, ldx, w, ldw, bias, gamma, res, ldr, out, ldo, M, N, K, act, 1, (K + 15) >> 4, nullptr};
+    const int tiles = ((N + 31) / 32) * ((M + 31) / 32), nchunks = (K + 15) >> 4;
+    // weight streaming needs many loads in flight: aim at >= 1024 workgroups (4 per CU), at least 8 chunks (one per wave) each
+    // (measured at M = 32, K = 2048: 64 tiles 21.6 -> 15.3 us, 32 tiles 21.5 -> 11.9, 64 tiles with K = 8192 74 -> 30;
+    //  192 / 256 tiles 22.7 -> 24.4 / 24.6 -> 27.5: the second launch costs more than the split gains there)
+    if (ws != nullptr && ((uintptr_t)ws % 16) == 0 && tiles < 128 && nchunks >= 16) {
+        int ks = (1024 + tiles - 1) / tiles;
+        if (ks > nchunks / 8) ks = nchunks / 8;
+        if (ks > 32) ks = 32;
+        const long need = LIN_WS_COUNTERS * 4 + (long)tiles * ks * 1024 * 4;
+        if (ks > 1 && need <= ws_bytes) {
+            p.ks = ks;
+            p.kchunks = (nchunks + ks - 1) / ks;
+            p.ks = (nchunks + p.kchunks - 1) / p.kchunks;   // no empty slice
+            p.part = (float*)((char*)ws + LIN_WS_COUNTERS * 4);
+        }
+    }
+    const dim3 grid((N + 31) / 32, (M + 31) / 32, p.ks), block(512);
     const bool aligned = (ldx % 4 == 0) && (ldw % 4 == 0) && (((uintptr_t)x | (uintptr_t)w) % 16 == 0);
     if (aligned) hipLaunchKernelGGL(linear_f32_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(linear_f32_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
+    if (p.ks > 1) {
+        const int tiles_n = (N + 31) / 32, tiles_m = (M + 31) / 32;
+        hipLaunchKernelGGL(linear_finalize_kernel, dim3((unsigned)(tiles_n * tiles_m * 4)), dim3(256), 0, (hipStream_t)stream, p,
+                           tiles_n);
+        IGGT_CHECK_LAUNCH();
+    }
     return 0;
 }
+
+extern "C" int iggt_linear_f32(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* gamma,
+                               const float* res, long ldr, float* out, long ldo, int M, int N, int K, int act,
+                               void* stream) {
+    return iggt_linear_f32_ws(x, ldx, w, ldw, bias, gamma, res, ldr, out, ldo, M, N, K, act, nullptr, 0, stream);
+}
+
+extern "C" long iggt_linear_f32_ws_bytes(void) { return LIN_WS_COUNTERS * 4 + 2048L * 1024 * 4; }
 
 extern "C" int iggt_attn_f32(const float* q, const float* k, const float* v, float* o, int B, int H, int Nq, int Nk,
                              int head_dim, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,

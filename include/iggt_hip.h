@@ -216,6 +216,15 @@ int iggt_bilinear_ac_nhwc_f32(const float* x, int ldx, float* y, int ldy, int N,
  * embed_pose, poseLN_modulation, pose_branch) and ChannelAttention's pooled 1x1 convs (iggt/heads/window_sa.py:26-37). */
 int iggt_linear_f32(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* gamma,
                     const float* res, long ldr, float* out, long ldo, int M, int N, int K, int act, void* stream);
+/* The same with a scratch buffer that lets the kernel split K over several workgroups per output tile (the op streams the
+ * fp32 weights once and needs >= ~1000 workgroups to keep enough loads in flight; a 2048 -> 2048 Linear has 64 tiles):
+ * ws = iggt_linear_f32_ws_bytes() bytes, 16-byte aligned, used by one call at a time (calls on one stream).  The partial
+ * sums are added in a fixed order by a second small kernel: results do not depend on scheduling.  ws == NULL: one
+ * workgroup per tile, as iggt_linear_f32. */
+int iggt_linear_f32_ws(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* gamma,
+                       const float* res, long ldr, float* out, long ldo, int M, int N, int K, int act, void* ws,
+                       long ws_bytes, void* stream);
+long iggt_linear_f32_ws_bytes(void);
 
 /* softmax(scale * q k^T) v in fp32, head_dim 32 / 64 / 128; element (b, h, n, d) at ptr + b*bs + n*rs + h*head_dim + d.
  * Replaces the attention core of the camera trunk (iggt/layers/attention.py:60-66 with 16 heads x 128 over the S views)

@@ -41,6 +41,10 @@ def test_linear_f32(C, M, N, K, act, extras):
     mx, l2 = _relerr(out, ref)
     report(f"linear_f32_{M}x{N}x{K}_{act}", dict(max=mx, l2=l2))
     assert mx < 1e-5, (mx, l2)
+    # split-K partial sums are added in a fixed order: bit-identical from launch to launch
+    a1 = C.linear_f32(x, w, b, act=act, gamma=gamma)
+    a2 = C.linear_f32(x, w, b, act=act, gamma=gamma)
+    assert torch.equal(a1, a2)
     # strided input rows (a column slice of a wider matrix)
     big = _rand((M, K + 8), 6)
     out2 = C.linear_f32(big[:, 4:4 + K] if K % 4 == 0 else big[:, :K], w, b)
