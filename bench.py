@@ -191,10 +191,18 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback for the product path)")
+    # developer switch (not a product path): IGGT_BENCH_SINGLE_DEVICE=1 runs all ranks on cuda:0 over gloo, so that the
+    # multi-rank control flow of this script can be exercised on a one-GPU box (RCCL refuses two ranks on one device)
+    single_dev = os.environ.get("IGGT_BENCH_SINGLE_DEVICE", "0") == "1"
+    if single_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     shard = None
-    if world > 1:
+    if world > 1 and single_dev:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 

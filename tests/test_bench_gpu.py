@@ -1,0 +1,54 @@
+"""GPU: the bench.py contract -- one JSON line with the roofline object, and the multi-rank control flow (two ranks on this
+one GPU over gloo: IGGT_BENCH_SINGLE_DEVICE=1; RCCL refuses two ranks on one device) with hipGraph segments, the
+max-over-ranks timing and the per-rank output check against the reference fixture."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _last_json(out):
+    lines = [ln for ln in out.strip().splitlines() if ln.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_single_gpu_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--views", "8", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["output_check"]["ok"]
+
+
+def test_bench_two_rank_control_flow():
+    env = dict(os.environ, IGGT_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--views", "8", "--steps", "1",
+           "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["graphs"] is True and "graphs_note" not in d
+    assert d["config"]["parallelism"] == "view-shard x2"
+    assert d["output_check"]["ok"] and d["output_check"]["max_l2_all_ranks"] < 1e-3
+    assert "cpu_baseline" not in d            # rank 0 at N = 1 only
