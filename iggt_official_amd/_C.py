@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -103,6 +103,18 @@ _SIGNATURES = {
     "iggt_stretch3_f32": [_c_void_p, _c_long, _c_void_p, _c_void_p],
     "iggt_nn1_label_f32": [_c_void_p, _c_long, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "iggt_count_saturated_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
+    "iggt_layernorm_rows_f32": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
+                                _c_int, _c_float, _c_void_p],
+    "iggt_avgpool2_nhwc_f32": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p],
+    "iggt_sample_points_nhwc_f32": [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_long, _c_void_p, _c_long, _c_int,
+                                    _c_void_p],
+    "iggt_track_corr_f32": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
+                            _c_void_p, _c_long, _c_void_p],
+    "iggt_track_posemb_f32": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_long, _c_void_p, _c_long, _c_int,
+                              _c_void_p],
+    "iggt_track_tokens_f32": [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_long, _c_int, _c_void_p, _c_long,
+                              _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_float, _c_void_p],
+    "iggt_track_update_f32": [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_int, _c_int, _c_float, _c_void_p],
     "iggt_write_special_tokens": [_c_void_p, _c_long, _c_long, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_void_p],
 }
@@ -708,3 +720,111 @@ def nn1_label(query, ref, ref_labels):
                                    ref_labels.data_ptr(), out.data_ptr(), _stream())
     _check(rc, "iggt_nn1_label_f32")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# track head (csrc/track.hip)
+def layernorm_rows(x, w, b, eps, out=None, add=None):
+    """LayerNorm over the last dim of x (+ add) [M, C] fp32 (unit column stride, any row stride / width)."""
+    _dev(x, w, b, out, add)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    M, C = x.shape
+    if add is not None:
+        assert add.dtype == torch.float32 and add.shape == (M, C) and add.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, C, dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.shape == (M, C) and out.stride(1) == 1
+    rc = load().iggt_layernorm_rows_f32(x.data_ptr(), x.stride(0), _ptr(add), 0 if add is None else add.stride(0),
+                                        _f32c(w, "weight").data_ptr(), _f32c(b, "bias").data_ptr(), out.data_ptr(),
+                                        out.stride(0), M, C, float(eps), _stream())
+    _check(rc, "iggt_layernorm_rows_f32")
+    return out
+
+
+def avgpool2_nhwc(x):
+    """x [N, H, W, C] fp32 contiguous -> [N, H // 2, W // 2, C]."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+    N, H, W, C = x.shape
+    y = torch.empty(N, H // 2, W // 2, C, dtype=torch.float32, device=x.device)
+    _check(load().iggt_avgpool2_nhwc_f32(x.data_ptr(), y.data_ptr(), N, H, W, C, _stream()), "iggt_avgpool2_nhwc_f32")
+    return y
+
+
+def sample_points_nhwc(feat, xy):
+    """feat [H, W, C] fp32 contiguous, xy [N, 2] pixel coordinates -> [N, C] (bilinear, border padding)."""
+    _dev(feat, xy)
+    assert feat.dtype == torch.float32 and feat.dim() == 3 and feat.is_contiguous()
+    assert xy.dtype == torch.float32 and xy.dim() == 2 and xy.shape[1] == 2 and xy.stride(1) == 1
+    H, W, C = feat.shape
+    N = xy.shape[0]
+    out = torch.empty(N, C, dtype=torch.float32, device=feat.device)
+    rc = load().iggt_sample_points_nhwc_f32(feat.data_ptr(), H, W, C, xy.data_ptr(), xy.stride(0), out.data_ptr(), C, N,
+                                            _stream())
+    _check(rc, "iggt_sample_points_nhwc_f32")
+    return out
+
+
+def track_corr(pyramid, feats, coords, radius, out):
+    """pyramid: list of [S, H_l, W_l, C] fp32 contiguous maps; feats [N, S, C], coords [N, S, 2] contiguous;
+    out [N * S, ld] with ld >= levels * (2 radius + 1)^2 (the padding columns are zeroed)."""
+    _dev(feats, coords, out, *pyramid)
+    L = len(pyramid)
+    S, _, _, C = pyramid[0].shape
+    N = feats.shape[0]
+    for t in list(pyramid) + [feats, coords, out]:
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    assert feats.shape == (N, S, C) and coords.shape == (N, S, 2) and out.shape[0] == N * S
+    ptrs = (ctypes.c_void_p * L)(*[m.data_ptr() for m in pyramid])
+    hs = (ctypes.c_int * L)(*[m.shape[1] for m in pyramid])
+    ws = (ctypes.c_int * L)(*[m.shape[2] for m in pyramid])
+    rc = load().iggt_track_corr_f32(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(hs, ctypes.c_void_p),
+                                    ctypes.cast(ws, ctypes.c_void_p), L, S, C, feats.data_ptr(), coords.data_ptr(), N,
+                                    radius, out.data_ptr(), out.stride(0), _stream())
+    _check(rc, "iggt_track_corr_f32")
+    return out
+
+
+def track_posemb(tabx, taby, xy):
+    """tabx [W, Ch], taby [H, Ch] fp32; xy [N, 2] -> [N, 2 Ch]."""
+    _dev(tabx, taby, xy)
+    for t in (tabx, taby):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    assert xy.dtype == torch.float32 and xy.stride(1) == 1
+    W, Ch = tabx.shape
+    H = taby.shape[0]
+    N = xy.shape[0]
+    out = torch.empty(N, 2 * Ch, dtype=torch.float32, device=xy.device)
+    rc = load().iggt_track_posemb_f32(tabx.data_ptr(), taby.data_ptr(), H, W, Ch, xy.data_ptr(), xy.stride(0),
+                                      out.data_ptr(), 2 * Ch, N, _stream())
+    _check(rc, "iggt_track_posemb_f32")
+    return out
+
+
+def track_tokens(coords, corr, feats, pos, ref, E, max_scale, out=None):
+    """coords [N, S, 2], corr [N * S, Cc], feats [N * S, Cf], pos [N, D], ref [2, D] -> [N * S, D], D = 2E + 4 + Cc + Cf."""
+    _dev(coords, corr, feats, pos, ref, out)
+    N, S, _ = coords.shape
+    Cc, Cf = corr.shape[1], feats.shape[1]
+    D = 2 * E + 4 + Cc + Cf
+    for t in (coords, corr, feats, pos, ref):
+        assert t.dtype == torch.float32 and t.stride(-1) == 1
+    assert coords.is_contiguous() and ref.is_contiguous() and pos.shape == (N, D) and ref.shape == (2, D)
+    if out is None:
+        out = torch.empty(N * S, D, dtype=torch.float32, device=coords.device)
+    rc = load().iggt_track_tokens_f32(coords.data_ptr(), corr.data_ptr(), corr.stride(0), Cc, feats.data_ptr(),
+                                      feats.stride(0), Cf, pos.data_ptr(), pos.stride(0), ref.data_ptr(), out.data_ptr(),
+                                      out.stride(0), N, S, E, float(max_scale), _stream())
+    _check(rc, "iggt_track_tokens_f32")
+    return out
+
+
+def track_update(coords, delta, pred, stride):
+    """coords [N, S, 2] (updated in place), delta [N * S, >= 2], pred [S, N, 2] (written)."""
+    _dev(coords, delta, pred)
+    N, S, _ = coords.shape
+    assert coords.is_contiguous() and pred.is_contiguous() and pred.shape == (S, N, 2) and delta.stride(1) == 1
+    rc = load().iggt_track_update_f32(coords.data_ptr(), delta.data_ptr(), delta.stride(0), pred.data_ptr(), N, S,
+                                      float(stride), _stream())
+    _check(rc, "iggt_track_update_f32")
+    return pred

@@ -202,6 +202,13 @@ class DPTHead(nn.Module):
             merged.append(tuple(torch.cat([p[2][i] for p in parts], 0) for i in range(3)))
         return tuple(merged)
 
+    def features_nhwc(self, aggregated_tokens_list, images, patch_start_idx, frames_chunk_size=FRAMES_CHUNK):
+        """for_tracker heads: the feature map as the kernels produce it, NHWC [S, H / down_ratio, W / down_ratio, C]
+        (`forward` returns the reference's [1, S, C, h, w] view of the same memory)."""
+        assert self.for_tracker
+        out = self.forward(aggregated_tokens_list, images, patch_start_idx, frames_chunk_size)
+        return out[0].permute(0, 2, 3, 1).contiguous()     # no copy: forward() permuted a contiguous NHWC tensor
+
     def _token_maps(self, tokens_list, psi, s0, s1, H, W):
         """projects -> (+pos) -> resize_layers, NHWC (reference dpt_head.py:225-244)."""
         gh, gw = H // self.patch_size, W // self.patch_size
@@ -225,7 +232,7 @@ class DPTHead(nn.Module):
         maps = self._token_maps(tokens_list, psi, s0, s1, H, W)
         out, side = self.scratch_forward(maps)
         size = (int(gh * self.patch_size / self.down_ratio), int(gw * self.patch_size / self.down_ratio))
-        c2 = self.scratch.output_conv2
+        c2 = None if self.for_tracker else self.scratch.output_conv2
         fused = (not self.for_tracker and FUSED_TAIL and out.shape[3] == 128 and c2[0].in_channels == 128
                  and c2[0].out_channels == 32 and c2[0].kernel_size == (3, 3) and c2[0].padding == (1, 1)
                  and c2[2].in_channels == 32 and 2 <= c2[2].out_channels <= 8

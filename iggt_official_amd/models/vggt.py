@@ -14,9 +14,9 @@ Deliberate differences, all documented in DESIGN.md:
   * `part_feat` needs H, W in 28N exactly like the reference (appendix D.2); for other sizes the
     reference raises inside the part head after having computed everything else -- here
     `IGGT(..., part_on_invalid_grid="skip")` (default "raise") returns the geometry outputs only;
-  * `track_head` (only run when `query_points` is given, vggt.py:220; demo never does) is not built:
-    its 134 checkpoint tensors are ignored by `load_state_dict(strict=False)` (what demo.py:116 uses)
-    and `query_points` raises NotImplementedError;
+  * `track_head` (only run when `query_points` is given, vggt.py:220-227): any number of views works (the reference's
+    default chunked feature extractor raises for S > 12); a forward with query points runs eagerly even when
+    `enable_graphs()` is on (the number of tracks is not part of a captured shape);
   * multi-GPU: `set_view_shard(ViewShard())` makes `forward` take this rank's slice of the views.
 """
 from typing import Optional
@@ -37,6 +37,7 @@ from ..heads.adaptor import SamProjector
 from ..heads.camera_head import CameraHead
 from ..heads.dpt_head import DPTHead
 from ..heads.part_head import PartHead
+from ..heads.track_head import TrackHead
 from .aggregator import Aggregator
 
 
@@ -65,8 +66,10 @@ class _Base(nn.Module, PyTorchModelHubMixin):
     def reset_graphs(self):
         self._gcache.reset()
 
-    def _dispatch(self, images, run):
+    def _dispatch(self, images, run, query_points=None):
         """run(images[1,S,3,H,W]) -> dict, eagerly or through the graph cache."""
+        if query_points is not None:
+            return run(images, query_points)
         if not self._graphs_on:
             return run(images)
         shard = self.aggregator.shard
@@ -85,9 +88,6 @@ class _Base(nn.Module, PyTorchModelHubMixin):
         return self._gcache.run(key, images, fwd)
 
     def _common(self, images, query_points):
-        if query_points is not None:
-            raise NotImplementedError("TrackHead / query_points is out of scope of the MI355X hot path "
-                                      "(reference vggt.py:220-227; demo.py never passes query_points)")
         if images.dim() == 4:
             images = images.unsqueeze(0)
         if images.dim() != 5:
@@ -98,10 +98,36 @@ class _Base(nn.Module, PyTorchModelHubMixin):
         _C.load()
         return images.float().contiguous()
 
+    @staticmethod
+    def _query(query_points, batch):
+        """reference vggt.py:59-60 / 192-193: [N, 2] -> [1, N, 2]; one set of points per scene."""
+        if query_points is None:
+            return None
+        if query_points.dim() == 2:
+            query_points = query_points.unsqueeze(0)
+        if query_points.dim() != 3 or query_points.shape[-1] != 2 or query_points.shape[0] != batch:
+            raise ValueError(f"query_points must be [N,2] or [B,N,2] with B = {batch}, got {tuple(query_points.shape)}")
+        return query_points
+
+    def _track(self, pred, tokens, images, psi, query_points):
+        """reference vggt.py:220-227: track of the last iteration, visibility, confidence."""
+        if query_points is None:
+            return
+        if self.track_head is None:
+            raise ValueError("this model was built without a track head")
+        shard = self.aggregator.shard
+        gather = shard.all_gather_rows if (shard is not None and shard.world > 1) else None
+        track_list, vis, conf = self.track_head(tokens, images=images, patch_start_idx=psi, query_points=query_points,
+                                                gather=gather)
+        pred["track"] = track_list[-1]
+        pred["vis"] = vis
+        pred["conf"] = conf
+
     def _scenes(self, images, query_points):
         """B > 1 (reference vggt.py:149: images [B,S,3,H,W]): scenes are independent, so they run one after the other
         through the single-scene path and the outputs are concatenated along the batch dimension."""
-        outs = [self.forward(images[b], query_points) for b in range(images.shape[0])]
+        outs = [self.forward(images[b], None if query_points is None else query_points[b:b + 1])
+                for b in range(images.shape[0])]
         pred = {}
         for k, v in outs[0].items():
             if k == "pose_enc":
@@ -128,14 +154,15 @@ class VGGT(_Base):
                                   use_point_feat=False)
         self.depth_head = DPTHead(dim_in=2 * embed_dim, output_dim=2, activation="exp", conf_activation="expp1",
                                   use_point_feat=False)
-        self.track_head = None
+        self.track_head = TrackHead(dim_in=2 * embed_dim, patch_size=patch_size)
         self._init_runtime()
 
-    def _run(self, images):
+    def _run(self, images, query_points=None):
         tokens, psi = self.aggregator(images)
         pred = {"pose_enc": self._camera(tokens)}
         pred["depth"], pred["depth_conf"] = self.depth_head(tokens, images=images, patch_start_idx=psi)
         pred["world_points"], pred["world_points_conf"] = self.point_head(tokens, images=images, patch_start_idx=psi)
+        self._track(pred, tokens, images, psi, query_points)
         pred["images"] = images
         return pred
 
@@ -143,9 +170,10 @@ class VGGT(_Base):
     def forward(self, images, query_points=None):
         with torch.amp.autocast("cuda", enabled=False):   # reference vggt.py:66
             images = self._common(images, query_points)
+            query_points = self._query(query_points, images.shape[0])
             if images.shape[0] != 1:
                 return self._scenes(images, query_points)
-            return self._dispatch(images, self._run)
+            return self._dispatch(images, self._run, query_points)
 
 
 class IGGT(_Base):
@@ -158,14 +186,14 @@ class IGGT(_Base):
                                   use_point_feat=True)
         self.depth_head = DPTHead(dim_in=2 * embed_dim, output_dim=2, activation="exp", conf_activation="expp1",
                                   use_point_feat=False)
-        self.track_head = None
+        self.track_head = TrackHead(dim_in=2 * embed_dim, patch_size=patch_size)
         self.part_adaptor = SamProjector(dim_in=2 * embed_dim, out_channels=[256, 256, 256, 256], pos_embed=False)
         self.part_head = PartHead(dim_in=2 * embed_dim, output_dim=8, activation="norm")
         assert part_on_invalid_grid in ("raise", "skip")
         self.part_on_invalid_grid = part_on_invalid_grid
         self._init_runtime()
 
-    def _run(self, images):
+    def _run(self, images, query_points=None):
         H, W = images.shape[-2:]
         part_ok = (H % 28 == 0) and (W % 28 == 0)
         tokens, psi = self.aggregator(images)
@@ -177,6 +205,7 @@ class IGGT(_Base):
             pyramid, _ = self.part_adaptor(tokens, images=images, patch_start_idx=psi)
             pred["part_feat"] = self.part_head(list(pyramid.values()), point_feature=point_feat, images=images,
                                                patch_start_idx=psi)
+        self._track(pred, tokens, images, psi, query_points)
         pred["images"] = images
         return pred
 
@@ -184,9 +213,11 @@ class IGGT(_Base):
     def forward(self, images, query_points=None):
         """images [S,3,H,W] or [1,S,3,H,W] in [0,1] (this rank's views when sharded) -> dict with
         pose_enc (list of 4 x [1,S_all,9]), depth [1,S,H,W,1], depth_conf [1,S,H,W],
-        world_points [1,S,H,W,3], world_points_conf [1,S,H,W], part_feat [1,S,8,H,W], images."""
+        world_points [1,S,H,W,3], world_points_conf [1,S,H,W], part_feat [1,S,8,H,W], images; with query_points
+        ([N,2] or [1,N,2] pixel (x, y) in view 0) also track [1,S,N,2], vis [1,S,N], conf [1,S,N]."""
         with torch.amp.autocast("cuda", enabled=False):   # reference vggt.py:189: the caller's autocast never reaches the kernels
             images = self._common(images, query_points)
+            query_points = self._query(query_points, images.shape[0])
             if images.shape[0] != 1:
                 return self._scenes(images, query_points)
             H, W = images.shape[-2:]
@@ -194,4 +225,4 @@ class IGGT(_Base):
             if not part_ok and self.part_on_invalid_grid == "raise":
                 raise ValueError(f"IGGT part head needs H, W multiples of 28, got {H}x{W} (the reference fails in "
                                  "window_sa.py:73); construct IGGT(part_on_invalid_grid='skip') for geometry only")
-            return self._dispatch(images, self._run)
+            return self._dispatch(images, self._run, query_points)

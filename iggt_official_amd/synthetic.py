@@ -78,6 +78,20 @@ def make_tensor(name: str, shape, seed: int, mode: str, device="cpu") -> torch.T
         return randn(0.1)
     if leaf == "relative_position_bias_table":
         return randn(0.5)
+    # track head (reference heads/track_modules/base_track_predictor.py:52, blocks.py:52 -- both torch.randn at init;
+    # nn.MultiheadAttention keeps its input projection as in_proj_weight / in_proj_bias)
+    if leaf in ("query_ref_token", "virual_tracks"):
+        return randn(1.0)
+    if leaf == "in_proj_bias":
+        return randn(0.1)
+    if leaf == "in_proj_weight":
+        return randn(shape[1] ** -0.5)
+    if name.endswith("updateformer.flow_head.weight"):
+        # the reference initialises this layer with std 0.001 (blocks.py:97).  The tracker feeds coordinate differences
+        # back through a sin / cos embedding of up to 969 rad per pixel (utils.py:107): with an O(1) flow head one
+        # refinement iteration amplifies a perturbation ~40x and four iterations turn fp32 rounding noise into 0.3 pixels
+        # in the REFERENCE itself; at std 0.005 an iteration moves a track by ~0.1-0.3 pixels and stays well-conditioned
+        return randn(0.005)
     if leaf == "bias":
         # norm-layer bias or linear/conv bias: small but non-zero
         return randn(0.1)
@@ -106,15 +120,15 @@ def _is_conv_transpose(name: str) -> bool:
     return tail.startswith(("0.", "1."))
 
 
-def fill_state_dict(schema: dict, seed: int = 0, mode: str = "stress", device="cpu") -> dict:
+def fill_state_dict(schema: dict, seed: int = 0, mode: str = "stress", device="cpu", include_track: bool = False) -> dict:
     """schema: {name: {"shape": [...], "dtype": "torch.float32"}} -> {name: tensor} for every
-    floating-point entry (integer buffers are left to the module that owns them)."""
+    floating-point entry (integer buffers are left to the module that owns them).  `track_head.*` is filled only on
+    request: it runs only when query_points is given (vggt.py:220) and costs 0.1 B hash draws otherwise."""
     out = {}
     for name, meta in schema.items():
         if not meta["dtype"].startswith("torch.float"):
             continue
-        if name.startswith("track_head."):
-            # TrackHead only runs when query_points is given (vggt.py:220); out of scope.
+        if name.startswith("track_head.") and not include_track:
             continue
         out[name] = make_tensor(name, meta["shape"], seed, mode, device)
     return out

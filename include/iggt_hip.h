@@ -309,6 +309,51 @@ int iggt_stretch3_f32(float* img, long M, const float* lohi, void* stream);
 int iggt_nn1_label_f32(const float* query, long Mq, const float* ref, long Mr, int C, const int* ref_labels, int* out,
                        void* stream);
 
+/* ---- track head: the query_points path of IGGT.forward (csrc/track.hip; reference iggt/models/vggt.py:220-227,
+ *      iggt/heads/track_head.py:75-109, iggt/heads/track_modules/) ------------------------------------------------------ */
+
+/* out[r][:] = LayerNorm(x[r][:] (+ x2[r][:] when x2 != NULL); w, b, eps) over rows of ANY width C (fp32, unaligned rows
+ * allowed; the optional addend is the `tokens + init_tokens` of blocks.py:139-142).  Replaces the
+ * nn.LayerNorm(388 / 384) layers of EfficientUpdateFormer / AttnBlock / CrossAttnBlock (track_modules/blocks.py:44,48,
+ * modules.py:168-169,203-205) and GroupNorm(1, 128) on a [rows][128] matrix (base_track_predictor.py:74,183). */
+int iggt_layernorm_rows_f32(const float* x, long ldx, const float* x2, long ldx2, const float* w, const float* b,
+                            float* out, long ldo, int rows, int C, float eps, void* stream);
+
+/* y[n][H/2][W/2][C] = 2 x 2 average pooling, stride 2 (floor sizes), NHWC fp32, C % 4 == 0.  Replaces F.avg_pool2d of
+ * CorrBlock's pyramid (track_modules/blocks.py:170-180). */
+int iggt_avgpool2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+
+/* out[n][0:C] = bilinear sample of feat [H][W][C] at pixel (xy[n][0], xy[n][1]), align_corners=True, border padding.
+ * Replaces sample_features4d / bilinear_sampler (track_modules/utils.py:124-226) for the query features. */
+int iggt_sample_points_nhwc_f32(const float* feat, int H, int W, int C, const float* xy, long ldxy, float* out,
+                                long ldo, int N, void* stream);
+
+/* CorrBlock.corr_sample (track_modules/blocks.py:189-241, compute_corr_level 244-249) without the correlation volume.
+ * fmaps / Hs / Ws: HOST arrays of `levels` device pointers / sizes, level l = [S][Hs[l]][Ws[l]][C] fp32 (NHWC pyramid);
+ * feats [N][S][C], coords [N][S][2] (level-0 pixels, x then y), both track-major.  out[(n*S + s)][l*(2r+1)^2 + ix*(2r+1) + iy]
+ * = bilinear sample (zero padding, align_corners) of <feats[n][s], fmap_l[s]> / sqrt(C) at coords / 2^l + (ix - r, iy - r);
+ * columns [levels*(2r+1)^2, ldo) are set to 0 (row padding for the Linear that follows).  C == 128, radius == 4. */
+int iggt_track_corr_f32(const float* const* fmaps, const int* Hs, const int* Ws, int levels, int S, int C,
+                        const float* feats, const float* coords, int N, int radius, float* out, long ldo, void* stream);
+
+/* out[n][0:2Ch] = get_2d_sincos_pos_embed(2Ch, (H, W)) sampled like sample_features4d at xy[n] (track_modules/utils.py:17-87,
+ * base_track_predictor.py:152-154).  tabx [W][Ch] / taby [H][Ch]: the 1-D tables [sin | cos](pos * omega) the 2-D one is
+ * built from (its first Ch channels depend on x only, the others on y only). */
+int iggt_track_posemb_f32(const float* tabx, const float* taby, int H, int W, int Ch, const float* xy, long ldxy,
+                          float* out, long ldo, int N, void* stream);
+
+/* Transformer input of one refinement iteration (base_track_predictor.py:139-163): row (n, s) =
+ * [get_2d_embedding(flow, E) (2E) | flow / max_scale (2) | flow / max_scale (2) | corr[n][s][0:Cc] | feats[n][s][0:Cf]]
+ * + pos[n][:] + ref[s > 0][:], flow = coords[n][s] - coords[n][0]; row width D = 2E + 4 + Cc + Cf. */
+int iggt_track_tokens_f32(const float* coords, const float* corr, long ldc, int Cc, const float* feats, long ldf, int Cf,
+                          const float* pos, long ldp, const float* ref, float* out, long ldo, int N, int S, int E,
+                          float max_scale, void* stream);
+
+/* coords[n][s] += delta[n][s][0:2] for s > 0 (frame 0 stays the query point); pred[s][n] = coords[n][s] * stride
+ * (base_track_predictor.py:168-195). */
+int iggt_track_update_f32(float* coords, const float* delta, long ldd, float* pred, int N, int S, float stride,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

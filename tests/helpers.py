@@ -14,10 +14,11 @@ def schema():
         return json.load(f)
 
 
-def build_gpu_model(mode="stress", seed=0, part_on_invalid_grid="skip"):
+def build_gpu_model(mode="stress", seed=0, part_on_invalid_grid="skip", include_track=False):
     """IGGT on cuda:0 filled with oracle.weights synthetic parameters (generated on-device by the
-    integer hash, bit-identical to the CPU values used for the golden fixtures)."""
-    key = (mode, seed, part_on_invalid_grid)
+    integer hash, bit-identical to the CPU values used for the golden fixtures).  The track head keeps its
+    constructor initialisation unless include_track (it only runs when query_points are passed)."""
+    key = (mode, seed, part_on_invalid_grid, include_track)
     if key in _MODELS:
         return _MODELS[key]
     from iggt.models.vggt import IGGT
@@ -26,10 +27,11 @@ def build_gpu_model(mode="stress", seed=0, part_on_invalid_grid="skip"):
     _MODELS.clear()  # one 1.3 B-parameter model resident at a time
     with torch.device("cuda"):
         model = IGGT(part_on_invalid_grid=part_on_invalid_grid).eval()
-    sd = weights.fill_state_dict(schema(), seed=seed, mode=mode, device="cuda")
+    sd = weights.fill_state_dict(schema(), seed=seed, mode=mode, device="cuda", include_track=include_track)
     missing, unexpected = model.load_state_dict(sd, strict=False)
-    assert not [u for u in unexpected if not u.startswith("track_head.")], unexpected
-    assert all("relative_position_index" in m or "num_batches_tracked" in m for m in missing), missing
+    assert not unexpected, unexpected
+    assert all("relative_position_index" in m or "num_batches_tracked" in m
+               or (m.startswith("track_head.") and not include_track) for m in missing), missing
     _MODELS[key] = model
     return model
 

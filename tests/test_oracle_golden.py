@@ -88,3 +88,38 @@ def test_golden_recipe_imports_the_reference_and_reproduces_a_fixture(tmp_path):
     for k, v in old.items():
         if torch.is_tensor(v):
             assert torch.equal(new[k], v), k
+
+
+# ------------------------------------------------------------------------------------------------
+# track head (query_points path): restatement oracle/restate_track.py against the reference's own TrackHead outputs
+TRACK_CASES = ["track_s3_140_stress", "track_s2_140x182_stress"]
+
+
+@pytest.fixture(scope="module")
+def sd_track(schema):
+    from oracle import weights
+
+    return weights.fill_state_dict(schema, seed=0, mode="stress", include_track=True)
+
+
+@pytest.mark.parametrize("case", TRACK_CASES)
+def test_track_restatement_matches_reference(sd_track, case):
+    from oracle import restate, restate_track, weights
+
+    g = load_golden(case)
+    m = g["meta"]
+    images = weights.make_images(m["S"], m["H"], m["W"], seed=m["image_seed"])
+    toks = restate.aggregator(sd_track, images)
+    taps = {}
+    preds, vis, conf = restate_track.track_head(sd_track, toks, m["H"], m["W"], g["query_points"], taps=taps)
+    _chk("fmaps", taps["fmaps"], g["fmaps"])
+    _chk("fcorrs_it0", taps["fcorrs_it0"], g["fcorrs_it0"])
+    _chk("delta_it0", taps["delta_it0"], g["delta_it0"], tol=2e-4)
+    # the flow embedding multiplies coordinate differences by up to 969 rad / pixel (utils.py:107): fp32 re-association
+    # noise of the first iteration (1e-6 pixels) comes back as 1e-3 rad phase noise in the second
+    _chk("coord_preds", torch.stack(preds, 0), g["coord_preds"], tol=2e-4)
+    _chk("vis", vis, g["vis"], tol=2e-3)
+    _chk("conf", conf, g["conf"], tol=2e-3)
+    # the tracker alone, fed with the reference's feature maps
+    preds2, vis2, conf2 = restate_track.tracker(sd_track, g["fmaps"], g["query_points"])
+    _chk("coord_preds (reference fmaps)", torch.stack(preds2, 0), g["coord_preds"], tol=2e-4)

@@ -9,12 +9,11 @@ def test_state_dict_matches_reference_schema(schema):
     with torch.device("meta"):
         model = IGGT()
     mine = {k: (list(v.shape), str(v.dtype)) for k, v in model.state_dict().items()}
-    ref = {k: (v["shape"], v["dtype"]) for k, v in schema.items() if not k.startswith("track_head.")}
-    assert sorted(mine) == sorted(ref)
+    ref = {k: (v["shape"], v["dtype"]) for k, v in schema.items()}
+    assert sorted(mine) == sorted(ref)            # all 2 053 tensors, track_head.* (394 of them) included
     for k in ref:
         assert mine[k] == ref[k], (k, mine[k], ref[k])
-    # track_head.* (TrackHead, only used with query_points) is out of scope: present in the reference schema, absent here
-    assert sum(1 for k in schema if k.startswith("track_head.")) == len(schema) - len(ref) > 0
+    assert sum(1 for k in mine if k.startswith("track_head.")) == 394 and len(mine) == 2053
 
 
 def test_relative_position_buffers_match_reference():

@@ -1,0 +1,312 @@
+"""Track head (query_points path, reference vggt.py:220-227 -> heads/track_head.py, heads/track_modules/) on the MI355X.
+
+Layers of evidence:
+  * every kernel of csrc/track.hip against the CPU restatement's function (oracle/restate_track.py, itself pinned to the
+    reference's TrackHead outputs by tests/test_oracle_golden.py) or plain torch, on shapes with odd sizes, points on and
+    beyond the border;
+  * the update transformer and its blocks (module API of the reference) against the restatement;
+  * the tracker fed with the REFERENCE's feature maps against the reference's coordinates of all four iterations,
+    visibility and confidence (fixtures of oracle/make_golden_track.py);
+  * single refinement iterations from a common state against the restatement;
+  * end to end: IGGT(images, query_points) / VGGT against the fixtures.
+"""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, load_golden, report
+from helpers import build_gpu_model, errors
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["track_s3_140_stress", "track_s2_140x182_stress"]
+
+
+@pytest.fixture(scope="module")
+def track_schema():
+    with open(os.path.join(GOLDEN, "state_dict_schema.json")) as f:
+        s = json.load(f)
+    return {k: v for k, v in s.items() if k.startswith("track_head.")}
+
+
+@pytest.fixture(scope="module")
+def sd_cpu(track_schema):
+    from oracle import weights
+
+    return weights.fill_state_dict(track_schema, seed=0, mode="stress", include_track=True)
+
+
+@pytest.fixture(scope="module")
+def head(sd_cpu):
+    from iggt.heads.track_head import TrackHead
+
+    with torch.device("cuda"):
+        th = TrackHead(dim_in=2048).eval()
+    missing, unexpected = th.load_state_dict({k[len("track_head."):]: v.cuda() for k, v in sd_cpu.items()}, strict=True)
+    assert not missing and not unexpected
+    return th
+
+
+def _rel(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+# ------------------------------------------------------------------------------------------------
+# kernels
+def test_layernorm_rows_any_width():
+    from iggt_official_amd import _C
+
+    torch.manual_seed(0)
+    for C in (388, 384, 128, 7, 130):
+        x = torch.randn(37, C + 5, device="cuda") * 3 + 1
+        w, b = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+        got = _C.layernorm_rows(x[:, 2:2 + C], w, b, 1e-5)          # unaligned row start, row stride > C
+        ref = F.layer_norm(x[:, 2:2 + C].double(), (C,), w.double(), b.double(), 1e-5)
+        assert _rel(got, ref) < 2e-6, C
+        add = torch.randn(37, C, device="cuda")
+        got = _C.layernorm_rows(x[:, 2:2 + C], w, b, 1e-5, add=add)
+        ref = F.layer_norm(x[:, 2:2 + C].double() + add.double(), (C,), w.double(), b.double(), 1e-5)
+        assert _rel(got, ref) < 2e-6, C
+    # GroupNorm(1, C) on a [M, C] matrix is the same function (base_track_predictor.py:74,183)
+    x = torch.randn(50, 128, device="cuda")
+    gn = torch.nn.GroupNorm(1, 128).cuda()
+    torch.nn.init.normal_(gn.weight), torch.nn.init.normal_(gn.bias)
+    assert _rel(_C.layernorm_rows(x, gn.weight.detach(), gn.bias.detach(), gn.eps), gn(x)) < 2e-6
+
+
+def test_avgpool2_matches_avg_pool2d():
+    from iggt_official_amd import _C
+
+    torch.manual_seed(1)
+    for (n, h, w, c) in ((2, 70, 91, 128), (3, 5, 2, 8), (1, 2, 3, 4)):
+        x = torch.randn(n, h, w, c, device="cuda")
+        got = _C.avgpool2_nhwc(x)
+        ref = F.avg_pool2d(x.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+        assert got.shape == ref.shape and _rel(got, ref) < 1e-6
+
+
+def _points(n, W, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([W + 12.0, H + 12.0]) - 6.0      # some outside on every side
+    xy[0] = torch.tensor([0.0, 0.0])
+    xy[1] = torch.tensor([W - 1.0, H - 1.0])
+    xy[2] = torch.tensor([W - 1.0, 3.5])
+    xy[3] = torch.tensor([2.0, 5.0])                                                   # integer coordinates
+    return xy
+
+
+def test_sample_points_matches_grid_sample_border():
+    from iggt_official_amd import _C
+    from oracle import restate_track
+
+    torch.manual_seed(2)
+    fm = torch.randn(1, 128, 35, 47)
+    xy = _points(200, 47, 35, 3)
+    ref = restate_track.sample_points(fm, xy[None])[0]
+    got = _C.sample_points_nhwc(fm[0].permute(1, 2, 0).contiguous().cuda(), xy.cuda())
+    # grid_sample maps pixels to [-1, 1] and back in fp32 (utils.py:176-189): ~1e-6 * W pixels of noise in the reference
+    assert _rel(got, ref) < 2e-5
+
+
+def test_posemb_matches_sampled_sincos_grid():
+    from iggt_official_amd import _C
+    from iggt_official_amd.heads.track_modules.utils import sincos_tables
+    from oracle import restate_track
+
+    HH, WW, D = 70, 91, 388
+    xy = _points(150, WW, HH, 4)
+    ref = restate_track.sample_points(restate_track.sincos_grid(D, HH, WW), xy[None])[0]
+    tabx, taby = sincos_tables(D, (HH, WW), torch.device("cuda"))
+    got = _C.track_posemb(tabx, taby, xy.cuda())
+    assert float((got.cpu() - ref).abs().max()) < 2e-5          # values in [-1, 1]; same coordinate noise as above
+
+
+@pytest.mark.parametrize("shape", [(2, 70, 91, 40), (3, 64, 64, 17)])
+def test_track_corr_matches_correlation_volume_sampling(shape):
+    """`iggt_track_corr_f32` (no correlation volume) == matmul + grid_sample of the reference (blocks.py:189-241)."""
+    from iggt_official_amd.heads.track_modules.blocks import CorrBlock
+    from oracle import restate_track
+
+    S, H, W, N = shape
+    torch.manual_seed(5)
+    fm = torch.randn(S, 128, H, W)
+    targets = torch.randn(S, N, 128)
+    coords = torch.stack([_points(N, W, H, 10 + s) for s in range(S)], 0)             # [S, N, 2]
+    coords[0, 4] = torch.tensor([-40.0, 1000.0])                                       # far outside
+    ref = restate_track.corr_sample(restate_track.corr_pyramid(fm, 7), targets, coords, 4)      # [S, N, 567]
+    cb = CorrBlock(fm.permute(0, 2, 3, 1).contiguous().cuda(), num_levels=7, radius=4)
+    assert [tuple(m.shape[1:3]) for m in cb.fmaps_pyramid] == [tuple(m.shape[-2:]) for m in
+                                                               restate_track.corr_pyramid(fm, 7)]
+    got = cb.corr_sample(targets.permute(1, 0, 2).contiguous().cuda(), coords.permute(1, 0, 2).contiguous().cuda())
+    assert got.shape == (N * S, 568) and float(got[:, 567].abs().max()) == 0.0
+    got = got[:, :567].view(N, S, 567).permute(1, 0, 2)
+    assert _rel(got, ref) < 2e-5
+    # a window far outside the map samples zeros -- except on the 1 x 1 top level(s), where the reference's sampler maps
+    # EVERY coordinate to pixel 0 (scale 2 / max(size - 1, 1), then grid_sample's (size - 1) / 2 = 0): reproduced
+    sizes = [min(m.shape[1:3]) for m in cb.fmaps_pyramid]
+    for l, sz in enumerate(sizes):
+        blk = got[0, 4, 81 * l:81 * (l + 1)]
+        assert (float(blk.abs().max()) == 0.0) == (sz > 1), (l, sz)
+
+
+def test_corr_pyramid_too_small_raises():
+    from iggt_official_amd.heads.track_modules.blocks import CorrBlock
+
+    with pytest.raises(RuntimeError):
+        CorrBlock(torch.randn(1, 28, 28, 128, device="cuda"), num_levels=7, radius=4)
+
+
+def test_track_tokens_and_update():
+    from iggt_official_amd import _C
+    from oracle import restate_track
+
+    torch.manual_seed(6)
+    N, S, C = 33, 4, 128
+    coords = torch.randn(N, S, 2) * 20 + 30
+    corr, feats = torch.randn(N * S, C), torch.randn(N * S, C)
+    pos, ref = torch.randn(N, 388), torch.randn(2, 388)
+    flows = coords - coords[:, :1]
+    femb = torch.cat([restate_track.flow_embedding(flows, 64), flows / 518, flows / 518], -1)
+    want = torch.cat([femb, corr.view(N, S, C), feats.view(N, S, C)], -1) + pos[:, None]
+    want = want + torch.cat([ref[:1], ref[1:2].expand(S - 1, -1)], 0)[None]
+    got = _C.track_tokens(coords.cuda(), corr.cuda(), feats.cuda(), pos.cuda(), ref.cuda(), 64, 518.0)
+    # sin / cos of arguments up to ~1e5 rad: both sides round the argument identically, the functions agree to ~1e-6
+    assert float((got.cpu().view(N, S, 388) - want).abs().max()) < 2e-5
+    delta = torch.randn(N * S, 130)
+    c2 = coords.clone().cuda()
+    pred = torch.empty(S, N, 2, device="cuda")
+    _C.track_update(c2, delta.cuda(), pred, 2.0)
+    want_c = coords + delta[:, :2].view(N, S, 2)
+    want_c[:, 0] = coords[:, 0]
+    assert torch.equal(c2.cpu(), want_c) and torch.equal(pred.cpu(), (want_c * 2).permute(1, 0, 2))
+
+
+# ------------------------------------------------------------------------------------------------
+# update transformer
+def test_attention_blocks_match_restatement(head, sd_cpu):
+    from oracle import restate_track
+
+    uf = head.tracker.updateformer
+    p = "track_head.tracker.updateformer"
+    torch.manual_seed(7)
+    x = torch.randn(5, 19, 384)
+    ctx = torch.randn(5, 70, 384)
+    got = uf.time_blocks[2](x.cuda())
+    assert _rel(got, restate_track.attn_block(sd_cpu, p + ".time_blocks.2", x)) < 2e-5
+    got = uf.space_virtual2point_blocks[1](x.cuda(), ctx.cuda())
+    assert _rel(got, restate_track.cross_block(sd_cpu, p + ".space_virtual2point_blocks.1", x, ctx)) < 2e-5
+
+
+def test_update_transformer_matches_restatement(head, sd_cpu):
+    from oracle import restate_track
+
+    torch.manual_seed(8)
+    N, S = 45, 3
+    x = torch.randn(N, S, 388)
+    ref = restate_track.update_former(sd_cpu, x)                      # [N, S, 130]
+    got, _ = head.tracker.updateformer(x[None].cuda())
+    assert got.shape == (1, N, S, 130)
+    e = errors(got[0], ref)
+    report("track/update_former", e)
+    assert e[1] < 2e-5 and e[0] < 1e-4, e
+
+
+# ------------------------------------------------------------------------------------------------
+# tracker against the reference's outputs
+@pytest.mark.parametrize("case", CASES)
+def test_tracker_on_reference_feature_maps(head, case):
+    g = load_golden(case)
+    coords, vis, conf = head.tracker(query_points=g["query_points"].cuda(), fmaps=g["fmaps"].cuda(), iters=4)
+    got = torch.stack(coords, 0)
+    assert got.shape == g["coord_preds"].shape and vis.shape == g["vis"].shape and conf.shape == g["conf"].shape
+    per_iter = [float((got[i].cpu() - g["coord_preds"][i]).abs().max()) for i in range(4)]
+    e = errors(got, g["coord_preds"])
+    report(f"track/{case}/tracker_on_ref_fmaps", dict(coords=e, max_abs_px_per_iter=per_iter,
+                                                      vis=errors(vis, g["vis"]), conf=errors(conf, g["conf"])))
+    assert per_iter[0] < 1e-3 and max(per_iter) < 2e-2, per_iter        # pixels (coordinates reach 140-180)
+    assert e[1] < 1e-4, e
+    assert errors(vis, g["vis"])[1] < 1e-3 and errors(conf, g["conf"])[1] < 1e-3
+
+
+def test_single_iterations_from_common_states(head, sd_cpu):
+    """Every refinement iteration checked on its own: the HIP tracker and the restatement start iteration k from the SAME
+    state (the restatement's), so that an error cannot hide behind, or be blamed on, the iterations before it."""
+    from oracle import restate_track
+
+    g = load_golden(CASES[1])
+    st_ref = restate_track.tracker_init(sd_cpu, g["fmaps"], g["query_points"])
+    st = head.tracker.prepare(g["query_points"].cuda(), g["fmaps"][0].permute(0, 2, 3, 1).contiguous().cuda())
+    assert _rel(st["pos"], st_ref["pos"]) < 2e-5 and _rel(st["feats"].permute(1, 0, 2), st_ref["feats"]) < 2e-5
+    for k in range(4):
+        st["coords"].copy_(st_ref["coords"].permute(1, 0, 2))
+        st["feats"].copy_(st_ref["feats"].permute(1, 0, 2))
+        taps = {}
+        want = restate_track.tracker_step(sd_cpu, st_ref, taps=taps)
+        got = head.tracker.refine(st)
+        N, S = st["N"], st["S"]
+        e_corr = _rel(st["fc_buf"][:, :567].view(N, S, 567), taps["fcorrs"])
+        e_delta = errors(st["delta"].view(N, S, 130), taps["delta"][0])
+        e_feat = errors(st["feats"].permute(1, 0, 2), st_ref["feats"])
+        report(f"track/step{k}", dict(corr=e_corr, delta=e_delta, feats=e_feat))
+        assert e_corr < 2e-5 and e_delta[1] < 1e-4 and e_feat[1] < 1e-4, (k, e_corr, e_delta, e_feat)
+        assert float((got.cpu() - want).abs().max()) < 2e-3, k
+
+
+# ------------------------------------------------------------------------------------------------
+# end to end
+@pytest.mark.parametrize("case", CASES)
+def test_forward_with_query_points_matches_reference(case):
+    from oracle import weights
+
+    g = load_golden(case)
+    m = g["meta"]
+    model = build_gpu_model(m["mode"], m["weight_seed"], include_track=True)
+    images = weights.make_images(m["S"], m["H"], m["W"], seed=m["image_seed"], device="cuda")
+    fm = model.track_head.feature_extractor(model.aggregator(images[None])[0], images[None], 5)
+    e_fm = errors(fm, g["fmaps"])
+    pred = model(images, query_points=g["query_points"][0].cuda())          # [N, 2] form (vggt.py:192-193)
+    assert set(pred) >= {"track", "vis", "conf", "depth", "world_points", "pose_enc"}
+    assert pred["track"].shape == (1, m["S"], m["n_query"], 2) and pred["track"].dtype == torch.float32
+    e = {k: errors(pred[k], ref) for k, ref in (("track", g["coord_preds"][-1]), ("vis", g["vis"]), ("conf", g["conf"]))}
+    px = float((pred["track"].cpu() - g["coord_preds"][-1]).abs().max())
+    report(f"track/{case}/e2e", dict(fmaps=e_fm, track=e["track"], vis=e["vis"], conf=e["conf"], track_max_abs_px=px))
+    assert e_fm[1] < 1e-3, e_fm                                             # feature maps: the 1e-3 bar of every head
+    # the tracks are pixel coordinates: 1e-3 relative and a bound in pixels (the 16-bit-operand trunk in front of the
+    # fp32 tracker perturbs the feature maps by ~3e-4)
+    assert e["track"][1] < 1e-3 and px < 0.25, (e["track"], px)
+    assert e["vis"][1] < 5e-3 and e["conf"][1] < 5e-3, e
+    # the geometry outputs do not depend on the presence of query points
+    plain = model(images)
+    assert "track" not in plain and torch.equal(plain["depth"], pred["depth"])
+
+
+def test_query_points_api_forms():
+    """[B, N, 2] with B scenes, VGGT, graphs on (runs eagerly), wrong shapes."""
+    from iggt.models.vggt import VGGT
+    from oracle import weights
+
+    g = load_golden(CASES[0])
+    m = g["meta"]
+    model = build_gpu_model(m["mode"], m["weight_seed"], include_track=True)
+    images = weights.make_images(m["S"], m["H"], m["W"], seed=m["image_seed"], device="cuda")
+    q = g["query_points"].cuda()
+    one = model(images, query_points=q)
+    two = model(torch.stack([images, images.flip(0)], 0), query_points=torch.cat([q, q[:, :7].repeat(1, 4, 1)[:, :24]], 0))
+    assert two["track"].shape == (2, m["S"], 24, 2) and torch.equal(two["track"][:1], one["track"])
+    with pytest.raises(ValueError):
+        model(images, query_points=q[0, :, :1])
+    model.enable_graphs(True)
+    try:
+        again = model(images, query_points=q)
+        assert torch.equal(again["track"], one["track"])
+    finally:
+        model.enable_graphs(False)
+    with torch.device("cuda"):
+        vggt = VGGT().eval()
+    vggt.load_state_dict(model.state_dict(), strict=False)
+    out = vggt(images, query_points=q)
+    assert torch.equal(out["track"], one["track"]) and torch.equal(out["vis"], one["vis"])
