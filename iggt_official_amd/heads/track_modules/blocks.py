@@ -110,7 +110,7 @@ class CorrBlock:
                                    f"{2 ** (num_levels - 1)} pixels a side, got {self.H} x {self.W}")
             self.fmaps_pyramid.append(_C.avgpool2_nhwc(cur))
         self.width = num_levels * (2 * radius + 1) ** 2
-        self.ld = (self.width + 3) // 4 * 4            # rows padded to 16 bytes for the Linear that reads them
+        self.ld = (self.width + 31) // 32 * 32         # zero-padded rows: aligned loads, K % 32 for the MFMA GEMM path
 
     def corr_sample(self, targets, coords, out=None):
         """targets [N, S, C], coords [N, S, 2] (track-major, level-0 pixels) -> [N * S, ld] (columns >= width are 0)."""

@@ -12,12 +12,20 @@ nothing is permuted.
 
 NB (modules.py:176-192): AttnBlock / CrossAttnBlock take their residual from the NORMALISED input, x = norm1(x); x = x +
 attn(x): reproduced."""
+import os
+
 import torch
 import torch.nn as nn
 
 from ... import _C
+from .. import convops as co
 
 HEAD_SLOT = 64
+# Linear layers over at least this many token rows run on the split-bf16 MFMA GEMM of the head convolutions (hi + lo
+# operands, three MFMAs per product: 4e-6 of fp64, csrc/conv_igemm.hip) instead of the exact-fp32 MFMA kernel, which is
+# built for a handful of rows (50 TF/s at 8 k rows against ~250).  0 = always exact fp32.
+SPLIT_ROWS = int(os.environ.get("IGGT_TRACK_SPLIT_ROWS", "4096"))
+_CONV_ACT = {None: 0, "gelu": 3}
 
 
 def _p(t):
@@ -37,6 +45,28 @@ class _PackCache:
             ent = (sig, make())
             self._d[key] = ent
         return ent[1]
+
+
+class PackedLinear:
+    """y = act(x W^T + b) (+ res) for a fixed fp32 weight [N, K]: exact fp32 MFMA for few rows, split-bf16 MFMA for many."""
+
+    def __init__(self, w, b):
+        self.w = w.detach().float().contiguous()
+        self.b = None if b is None else b.detach().float().contiguous()
+        self._pc = None
+
+    def __call__(self, x, act=None, res=None, out=None):
+        M, K = x.shape
+        N = self.w.shape[0]
+        if (SPLIT_ROWS and M >= SPLIT_ROWS and K % 32 == 0 and N % 4 == 0 and act in _CONV_ACT and x.is_contiguous()
+                and (res is None or res.is_contiguous()) and (out is None or out.is_contiguous())):
+            if self._pc is None:
+                self._pc = co.PackedConv(self.w, self.b, 1, 1, 1, 0, 0, K)
+            y = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=x.device)
+            co.run(self._pc, x.view(1, 1, M, K), out=y.view(1, 1, M, N), act=_CONV_ACT[act],
+                   res=None if res is None else res.view(1, 1, M, N))
+            return y
+        return _C.linear_f32(x, self.w, self.b, act=act, res=res, out=out)
 
 
 def pad_heads_rows(w, b, heads, d):
@@ -74,13 +104,14 @@ class Mlp(nn.Module):
 
     def forward_rows(self, x, res=None, out=None):
         """x [M, K] fp32 (any row stride) -> fc2(gelu(fc1 x)) (+ res) [M, out]."""
-        K = self.fc1.in_features
-        w1 = _p(self.fc1.weight)
-        if x.shape[1] != K:     # rows padded to a multiple of 4 floats (aligned loads): zero columns in the weight
-            w1 = self._pk.get("w1", (self.fc1.weight,), lambda: torch.nn.functional.pad(
-                self.fc1.weight.detach().float(), (0, x.shape[1] - K)).contiguous())
-        h = _C.linear_f32(x, w1, _p(self.fc1.bias), act="gelu")
-        return _C.linear_f32(h, _p(self.fc2.weight), _p(self.fc2.bias), res=res, out=out)
+        K, Kx = self.fc1.in_features, x.shape[1]
+
+        def make():   # x rows may be zero-padded (aligned loads, K % 32 for the MFMA path): zero columns in the weight
+            w1 = torch.nn.functional.pad(self.fc1.weight.detach().float(), (0, Kx - K))
+            return PackedLinear(w1, self.fc1.bias), PackedLinear(self.fc2.weight, self.fc2.bias)
+
+        l1, l2 = self._pk.get(Kx, (self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias), make)
+        return l2(l1(x, act="gelu"), res=res, out=out)
 
     def forward(self, x):
         shp = x.shape
@@ -112,8 +143,8 @@ class _MhaPacks:
             wqkv = torch.cat([wq, wkv], 0).contiguous()
             bqkv = torch.cat([bq, bkv], 0).contiguous()
             wo = pad_heads_cols(m.out_proj.weight, H, d)
-            return dict(wq=wq.contiguous(), bq=bq.contiguous(), wkv=wkv, bkv=bkv, wqkv=wqkv, bqkv=bqkv, wo=wo,
-                        bo=m.out_proj.bias.detach().float().contiguous(), scale=d ** -0.5, HS=H * HEAD_SLOT)
+            return dict(q=PackedLinear(wq, bq), kv=PackedLinear(wkv, bkv), qkv=PackedLinear(wqkv, bqkv),
+                        o=PackedLinear(wo, m.out_proj.bias), scale=d ** -0.5, HS=H * HEAD_SLOT)
 
         return self._pk.get(0, (m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias), make)
 
@@ -133,13 +164,13 @@ class AttnBlock(nn.Module):
         pk = self._packs.get()
         H, HS = self.attn.num_heads, pk["HS"]
         xn = _ln(self.norm1, x)
-        qkv = _C.linear_f32(xn, pk["wqkv"], pk["bqkv"])                      # [M, 3 HS]
+        qkv = pk["qkv"](xn)                                                    # [M, 3 HS]
         ao = torch.empty(x.shape[0], HS, dtype=torch.float32, device=x.device)
         ld = 3 * HS
         _C.attn_f32(qkv, qkv[:, HS:], qkv[:, 2 * HS:], ao, batch, H, length, length, HEAD_SLOT,
                     batch_stride * ld, row_stride * ld, batch_stride * ld, row_stride * ld, batch_stride * ld,
                     row_stride * ld, batch_stride * HS, row_stride * HS, pk["scale"])
-        _C.linear_f32(ao, pk["wo"], pk["bo"], res=xn, out=xn)                 # x = norm1(x) + attn
+        pk["o"](ao, res=xn, out=xn)                                           # x = norm1(x) + attn
         self.mlp.forward_rows(_ln(self.norm2, xn), res=xn, out=x)             # x = x + mlp(norm2 x)
         return x
 
@@ -167,13 +198,13 @@ class CrossAttnBlock(nn.Module):
         H, HS = self.cross_attn.num_heads, pk["HS"]
         xn = _ln(self.norm1, x)
         cn = _ln(self.norm_context, ctx)
-        q = _C.linear_f32(xn, pk["wq"], pk["bq"])                             # [Mq, HS]
-        kv = _C.linear_f32(cn, pk["wkv"], pk["bkv"])                          # [Mk, 2 HS]
+        q = pk["q"](xn)                                                       # [Mq, HS]
+        kv = pk["kv"](cn)                                                     # [Mk, 2 HS]
         ao = torch.empty(x.shape[0], HS, dtype=torch.float32, device=x.device)
         _C.attn_f32(q, kv, kv[:, HS:], ao, batch, H, len_q, len_k, HEAD_SLOT,
                     q_strides[0] * HS, q_strides[1] * HS, k_strides[0] * 2 * HS, k_strides[1] * 2 * HS,
                     k_strides[0] * 2 * HS, k_strides[1] * 2 * HS, q_strides[0] * HS, q_strides[1] * HS, pk["scale"])
-        _C.linear_f32(ao, pk["wo"], pk["bo"], res=xn, out=xn)
+        pk["o"](ao, res=xn, out=xn)
         self.mlp.forward_rows(_ln(self.norm2, xn), res=xn, out=x)
         return x
 

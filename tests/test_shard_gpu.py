@@ -44,7 +44,8 @@ def _worker(rank, world, port, case, kv_groups, graphs, overlap, ret):
         torch.cuda.set_device(0)
         g = load_golden(case)
         m = g["meta"]
-        model = build_gpu_model(m["mode"], m["weight_seed"])
+        track = "query_points" in g            # track fixtures: the query_points path, feature maps gathered over ranks
+        model = build_gpu_model(m["mode"], m["weight_seed"], include_track=track)
         shard = ViewShard(kv_groups=kv_groups)   # 1: one gather (default); 4: gather pipelined over head groups
         assert shard.kv_groups == kv_groups
         model.set_view_shard(shard)
@@ -53,7 +54,7 @@ def _worker(rank, world, port, case, kv_groups, graphs, overlap, ret):
         if graphs:   # hipGraph segments with the collectives as eager steps between them (iggt_official_amd/graphs.py)
             model.enable_graphs(True)
             model(images)                       # capture
-        pred = model(images)                    # graphs: replay
+        pred = model(images, query_points=g["query_points"].cuda()) if track else model(images)   # graphs: replay
         torch.cuda.synchronize()
         if graphs:
             seg = next(iter(model._gcache._graphs.values()))[1]
@@ -64,7 +65,12 @@ def _worker(rank, world, port, case, kv_groups, graphs, overlap, ret):
         for k in ("depth", "depth_conf", "world_points", "world_points_conf", "part_feat"):
             if k in g:
                 res[k] = errors(pred[k], g[k][:, v0:v1])[1]
-        res["pose_enc"] = errors(torch.stack(pred["pose_enc"], 0), g["pose_enc"])[1]   # all views on every rank
+        if track:                              # every rank tracks over ALL views
+            res["track"] = errors(pred["track"], g["coord_preds"][-1])[1]
+            res["vis"] = errors(pred["vis"], g["vis"])[1] / 5       # gated at 5e-3 like the unsharded run
+            res["conf"] = errors(pred["conf"], g["conf"])[1] / 5
+        else:
+            res["pose_enc"] = errors(torch.stack(pred["pose_enc"], 0), g["pose_enc"])[1]   # all views on every rank
         ret[rank] = res
     finally:
         dist.destroy_process_group()
@@ -74,7 +80,8 @@ def _worker(rank, world, port, case, kv_groups, graphs, overlap, ret):
                                                            ("tiny_s2_56_stress", 1, False, False),
                                                            ("tiny_s2_56_stress", 1, False, True),
                                                            ("tiny_s2_56_stress", 1, True, True),
-                                                           ("tiny_s2_56_stress", 1, True, False)])
+                                                           ("tiny_s2_56_stress", 1, True, False),
+                                                           ("track_s2_140x182_stress", 1, False, True)])
 def test_two_rank_sharded_forward_matches_reference(case, kv_groups, graphs, overlap):
     """kv_groups 4: gather pipelined over head groups (online-max kernel); kv_groups 1: one gather, static-bound attention --
     either gather -> one launch, or (overlap) own keys while the gather is in flight, then the other rank's keys, one slot
