@@ -1,7 +1,7 @@
 """IGGT / VGGT model API -- drop-in for `from iggt.models.vggt import IGGT, VGGT` (reference
 iggt/models/vggt.py:14-230; caller: demo.py:35,102-121,195).
 
-Same constructor, sub-module attribute names, state-dict keys (track_head excepted, see below) and
+Same constructor, sub-module attribute names, state-dict keys (all 2 053 tensors) and
 output dict (keys, shapes, fp32) as the reference; the forward runs on MI355X HIP kernels (aggregator, DPT / part /
 adaptor / camera heads: csrc/*.hip behind include/iggt_hip.h).  There is no CPU path: inputs and parameters must live on
 the GPU and libiggt_hip.so must be built, otherwise forward raises.  Like the reference (vggt.py:66,189) the forward runs
