@@ -205,6 +205,13 @@ def main():
     elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    # developer switch: IGGT_FORCE_COLLECTIVES=1 at N = 1 runs the sharded code path with its real RCCL calls in a world of
+    # one rank (everything but transport between devices): what the collectives cost per forward on this hardware
+    force_coll = world == 1 and os.environ.get("IGGT_FORCE_COLLECTIVES", "0") == "1"
+    if force_coll:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     from iggt.models.vggt import IGGT
     from iggt_official_amd import _C, precision, profiling, synthetic
@@ -217,7 +224,7 @@ def main():
     torch.manual_seed(0)  # identical weights on every rank
     with torch.device(dev):
         model = IGGT(part_on_invalid_grid="skip").eval()
-    if world > 1:
+    if world > 1 or force_coll:
         shard = ViewShard()
         model.set_view_shard(shard)
     v0, v1 = view_partition(S, world, rank)
@@ -318,6 +325,8 @@ def main():
             "data": data,
             "graphs": bool(graphs),
             **({"graphs_note": graph_note} if graph_note else {}),
+            **({"collectives": "forced: RCCL (backend nccl) in a world of one rank -- every all-gather of the sharded path "
+                               "is issued, nothing leaves the device"} if force_coll else {}),
             "config": {"workload": f"{S} views @ {H}x{H}, IGGT forward (DINOv2 + 24x(frame,global) + camera/depth/"
                                    "point heads), synthetic weights, views sharded " + f"{S // world}/GPU",
                        "views": S, "image_size": H, "tokens_per_view": P, "parallelism": f"view-shard x{world}"},
@@ -349,7 +358,7 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_coll:
         dist.destroy_process_group()
 
 

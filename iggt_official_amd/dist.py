@@ -39,20 +39,31 @@ def view_partition(S: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 class ViewShard:
-    def __init__(self, group: Optional["dist.ProcessGroup"] = None, kv_groups: Optional[int] = None):
+    def __init__(self, group: Optional["dist.ProcessGroup"] = None, kv_groups: Optional[int] = None,
+                 force: Optional[bool] = None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        # force (IGGT_FORCE_COLLECTIVES=1): issue every collective of the sharded path even in a world of ONE rank.  A
+        # one-GPU box can then run the real RCCL calls (communicator set-up, 16-bit all_gather_into_tensor, asynchronous
+        # work handles, the eager steps between hipGraph segments) and time their per-call overhead -- everything but the
+        # transport itself (tests/test_shard_gpu.py::test_rccl_world_of_one, bench.py).
+        self.force = (os.environ.get("IGGT_FORCE_COLLECTIVES", "0") == "1") if force is None else bool(force)
         self._bufs = {}
         g = int(os.environ.get("IGGT_KV_GROUPS", "1")) if kv_groups is None else int(kv_groups)
         if g not in (1, 2, 4, 8, 16):
             raise ValueError("kv_groups must divide the 16 heads")
-        self.kv_groups = g if self.world > 1 else 1
+        self.kv_groups = g if self.active else 1
         self._streams: List = []
         self._events: List = []
         self.ctl = None   # graphs.SegmentedGraph while a forward is being captured: collectives become eager steps
+
+    @property
+    def active(self) -> bool:
+        """True when the collectives of the sharded path have to be issued."""
+        return self.world > 1 or self.force
 
     def local_views(self, S: int) -> Tuple[int, int]:
         return view_partition(S, self.world, self.rank)

@@ -244,7 +244,7 @@ class Block(nn.Module):
                 if static:   # keys of the other ranks: the data-independent bound instead of this rank's maximum
                     qkmax[16:32].copy_(pk["k_bound"])
                 assert batch == 1
-                if static and q_rows_per_wg == 0 and hasattr(kv_gather, "all_gather_kv_begin") and kv_gather.world > 1 \
+                if static and q_rows_per_wg == 0 and hasattr(kv_gather, "all_gather_kv_begin") and kv_gather.active \
                         and precision.gather_overlap():
                     overlapped = self._attend_overlapped(qkv, kv_local, kv_gather, qkmax, ao, ws, T, H, C)
                 else:

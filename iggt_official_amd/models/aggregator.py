@@ -123,7 +123,7 @@ class Aggregator(nn.Module):
         if self.rope is not None:
             cos, sin = self.rope.tables(self.frame_blocks[0].attn.head_dim, max(gh, gw), dev)
             rope_geom = dict(P=P, gw=gw, patch_start=psi, cos=cos, sin=sin)
-        kv_gather = self.shard if (self.shard is not None and self.shard.world > 1) else None
+        kv_gather = self.shard if (self.shard is not None and self.shard.active) else None
 
         x2d = tokens.view(T, C)
         keep = self._keep()

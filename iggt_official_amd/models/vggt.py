@@ -116,7 +116,7 @@ class _Base(nn.Module, PyTorchModelHubMixin):
         if self.track_head is None:
             raise ValueError("this model was built without a track head")
         shard = self.aggregator.shard
-        gather = shard.all_gather_rows if (shard is not None and shard.world > 1) else None
+        gather = shard.all_gather_rows if (shard is not None and shard.active) else None
         track_list, vis, conf = self.track_head(tokens, images=images, patch_start_idx=psi, query_points=query_points,
                                                 gather=gather)
         pred["track"] = track_list[-1]
@@ -139,7 +139,7 @@ class _Base(nn.Module, PyTorchModelHubMixin):
     def _camera(self, tokens_list):
         shard = self.aggregator.shard
         cam = None
-        if shard is not None and shard.world > 1:
+        if shard is not None and shard.active:
             local = tokens_list[-1][0, :, 0]                      # [S_local, 2C]
             cam = shard.all_gather_rows(local)[None]               # [1, S, 2C]
         return self.camera_head(tokens_list, camera_tokens=cam)

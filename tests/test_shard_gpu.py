@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, kv_groups, graphs, overlap, ret):
+def _worker(rank, world, port, case, kv_groups, graphs, overlap, ret, backend="gloo"):
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
@@ -31,7 +31,11 @@ def _worker(rank, world, port, case, kv_groups, graphs, overlap, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":      # RCCL: one rank per device -- only a world of one fits a one-GPU box
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from conftest import load_golden
         from helpers import build_gpu_model, errors
@@ -46,7 +50,8 @@ def _worker(rank, world, port, case, kv_groups, graphs, overlap, ret):
         m = g["meta"]
         track = "query_points" in g            # track fixtures: the query_points path, feature maps gathered over ranks
         model = build_gpu_model(m["mode"], m["weight_seed"], include_track=track)
-        shard = ViewShard(kv_groups=kv_groups)   # 1: one gather (default); 4: gather pipelined over head groups
+        # kv_groups 1: one gather (default); 4: gather pipelined over head groups.  A world of one issues its collectives anyway
+        shard = ViewShard(kv_groups=kv_groups, force=(world == 1))
         assert shard.kv_groups == kv_groups
         model.set_view_shard(shard)
         v0, v1 = shard.local_views(m["S"])
@@ -94,3 +99,18 @@ def test_two_rank_sharded_forward_matches_reference(case, kv_groups, graphs, ove
     for rank, res in ret.items():
         for k, l2 in res.items():
             assert l2 < 1e-3, (rank, k, l2)   # same gate as the unsharded run (fp16 operands)
+
+
+@pytest.mark.parametrize("kv_groups,graphs,overlap", [(1, False, False), (1, False, True), (1, True, True), (4, False, False)])
+def test_rccl_world_of_one(kv_groups, graphs, overlap):
+    """The REAL RCCL calls of the sharded path on the one GPU this box has: backend "nccl", a world of one rank that issues
+    every collective regardless (ViewShard(force=True)): communicator set-up with device_id, all_gather_into_tensor on the
+    16-bit K/V buffers (synchronous, asynchronous with work.wait() for the overlapped variant, per head group), the fp32
+    camera-token gather, and the collectives as eager steps between hipGraph segments.  What it cannot show is transport
+    between devices; outputs must match the reference fixture as in the unsharded run."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(1, _free_port(), "tiny_s2_56_stress", kv_groups, graphs, overlap, ret, "nccl"), nprocs=1, join=True)
+    assert set(ret.keys()) == {0}
+    for k, l2 in ret[0].items():
+        assert l2 < 1e-3, (k, l2)
