@@ -9,7 +9,6 @@ ConvTranspose2d(k4,s2,p1) is four 2x2 parity convolutions, ConvTranspose2d(k2,s2
 The reference also evaluates a SAM-2 sine position encoding whose result is discarded by the caller
 (adaptor.py:223, vggt.py:208): it is not computed here and `pos` is returned as an empty dict.
 """
-import torch
 import torch.nn as nn
 
 from . import convops as co

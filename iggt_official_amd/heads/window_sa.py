@@ -21,7 +21,6 @@ PyTorch-ROCm ops: OCAB's query scramble (one permuted copy), CAB's squeeze-excit
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import _C
 from . import convops as co

@@ -23,7 +23,6 @@ import torch.nn as nn
 
 from .. import _C
 from ..layers.blocks import Block, Workspace
-from ..layers.patch_embed import PatchEmbed
 from ..layers.rope import PositionGetter, RotaryPositionEmbedding2D
 from ..layers.vision_transformer import vit_base, vit_giant2, vit_large, vit_small
 from ..dist import ViewShard

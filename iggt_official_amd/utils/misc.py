@@ -15,7 +15,7 @@ Same names, argument meaning and return shapes as the reference functions; the a
   as the reference imports them, else scikit-learn's implementation); the nearest-labelled-pixel fill of the noise pixels and
   the colouring run on the GPU.
 """
-from typing import Optional, Tuple, Union
+from typing import Tuple, Union
 
 import numpy as np
 import torch

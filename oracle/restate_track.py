@@ -10,7 +10,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from .restate import LAYERS, _conv, _convT, _fusion, _lin, _ln, _token_maps
+from .restate import _conv, _convT, _fusion, _lin, _ln, _token_maps
 
 P = "track_head.tracker"
 

@@ -67,6 +67,23 @@ def test_attn_f32(C, B, H, Nq, Nk, d):
     assert not torch.isnan(o).any() and mx < 2e-5, (mx, l2)
 
 
+@pytest.mark.parametrize("B,L", [(700, 8), (1088, 3), (600, 16), (64, 32), (300, 32)])
+def test_attn_f32_many_short_sequences(C, B, L):
+    """B x 8 sequences of L <= 32 tokens, head slot 64 (the tracker's attention along time, packed [B*L, 3*512] qkv with a
+    peaked row): B * H >= 512 with L <= 16 takes the one-thread-per-query-row kernel, the rest the MFMA kernel -- same contract."""
+    H, d = 8, 64
+    HS = H * d
+    qkv = _rand((B * L, 3 * HS), 41)
+    qkv.view(B, L, 3, H, d)[5, 1, 1, 2] = qkv.view(B, L, 3, H, d)[5, 0, 0, 2] * 4.0
+    o = torch.full((B * L, HS), float("nan"), device="cuda")
+    ld = 3 * HS
+    C.attn_f32(qkv, qkv[:, HS:], qkv[:, 2 * HS:], o, B, H, L, L, d, L * ld, ld, L * ld, ld, L * ld, ld, L * HS, HS, 48 ** -0.5)
+    x = qkv.double().view(B, L, 3, H, d)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 48 ** -0.5, -1) @ v).transpose(1, 2).reshape(B * L, HS)
+    assert not torch.isnan(o).any() and _relerr(o, ref)[0] < 2e-5
+
+
 def test_attn_f32_packed_qkv_and_peaked(C):
     """q/k/v as column slices of one [N, 3C] matrix (camera trunk layout); one key 30 nats above the rest."""
     N, H, d = 32, 16, 128
