@@ -274,6 +274,22 @@ def test_tracker_at_baseline_map_size_matches_restatement(head, sd_cpu):
     assert errors(vis, vis_w)[1] < 2e-3 and errors(conf, conf_w)[1] < 2e-3
 
 
+@pytest.mark.parametrize("S,N,iters", [(1, 1, 4), (1, 5, 2), (2, 1, 6), (17, 3, 1)])
+def test_tracker_edge_shapes(head, sd_cpu, S, N, iters):
+    """One view, one track, more / fewer refinement iterations than the default, the smallest legal map (64 pixels a side)."""
+    from oracle import restate_track
+
+    torch.manual_seed(100 + S + N)
+    fm = torch.randn(1, S, 128, 64, 80)
+    q = torch.rand(1, N, 2) * torch.tensor([158.0, 126.0])
+    want, vis_w, conf_w = restate_track.tracker(sd_cpu, fm, q, iters=iters)
+    got, vis, conf = head.tracker(query_points=q.cuda(), fmaps=fm.cuda(), iters=iters)
+    assert len(got) == iters and got[-1].shape == (1, S, N, 2) and vis.shape == (1, S, N)
+    assert float((got[0].cpu() - want[0]).abs().max()) < 1e-3
+    assert float((got[-1].cpu() - want[-1]).abs().max()) < (0.05 if iters > 2 else 5e-3)
+    assert float((vis.cpu() - vis_w).abs().max()) < 5e-3 and float((conf.cpu() - conf_w).abs().max()) < 5e-3
+
+
 def test_single_iterations_from_common_states(head, sd_cpu):
     """Every refinement iteration checked on its own: the HIP tracker and the restatement start iteration k from the SAME
     state (the restatement's), so that an error cannot hide behind, or be blamed on, the iterations before it."""
