@@ -12,7 +12,7 @@ SIZE = int(sys.argv[3]) if len(sys.argv) > 3 else 518
 
 
 class FakeShard:
-    rank, world = 0, N
+    rank, world, active = 0, N, True
     kv_groups = int(os.environ.get("IGGT_KV_GROUPS", "1"))
     _streams, _events = [], []
 
