@@ -64,6 +64,23 @@ def test_product_raises_without_gpu():
                      torch.zeros(4, 4))
 
 
+def test_track_head_raises_without_gpu():
+    """The query_points path has no CPU fallback either: tracker and sampling kernels refuse CPU tensors."""
+    import torch
+
+    from iggt.heads.track_modules.base_track_predictor import BaseTrackerPredictor
+    from iggt.heads.track_modules.blocks import CorrBlock
+    from iggt_official_amd import _C
+
+    tr = BaseTrackerPredictor(stride=2, corr_levels=7, hidden_size=384, latent_dim=128).eval()
+    with pytest.raises(_C.HipExtensionError):
+        tr(query_points=torch.zeros(1, 3, 2), fmaps=torch.zeros(1, 2, 128, 64, 64), iters=1)
+    with pytest.raises(_C.HipExtensionError):
+        CorrBlock(torch.zeros(2, 64, 64, 128), num_levels=7, radius=4)
+    with pytest.raises(_C.HipExtensionError):
+        tr.updateformer(torch.zeros(1, 3, 2, 388))
+
+
 def test_product_does_not_import_oracle():
     """The oracle is test infrastructure: nothing under the product packages may reference it."""
     bad = []
