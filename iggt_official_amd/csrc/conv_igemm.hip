@@ -489,10 +489,24 @@ extern "C" int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, c
     }
     const bool use_big = big && prec == 3 && (Cout % 256) == 0 && ((p.M + 255) / 256) * (Cout / 256) >= 2L * cus;
     int rc;
+    // Few output pixels (the 19^2 / 37^2 maps of a handful of views: the demo's 3-4 images, one rank of an 8-GPU run): the
+    // 128 x 128 tiling leaves most CUs idle while every workgroup walks a long K (1024 channels x 9 taps = 288 chunks).
+    // Narrower column tiles (128 x 64, 128 x 32) multiply the workgroups; the activation split per MFMA they add back is
+    // cheaper than idle CUs.  IGGT_CONV_NARROW=0 restores the fixed choice.
+    static int narrow = -1;
+    if (narrow < 0) {
+        const char* e = getenv("IGGT_CONV_NARROW");
+        narrow = (e && e[0] == '0') ? 0 : 1;
+    }
+    int bn = Cout > 64 ? 128 : Cout > 32 ? 64 : 32;
+    if (narrow && prec == 3 && !use_big) {
+        const long tiles_m = (p.M + 127) / 128;
+        while (bn > 32 && tiles_m * ((Cout + bn - 1) / bn) * 4 < 3L * cus) bn >>= 1;   // fewer than 3/4 of the CUs busy
+    }
     if (prec == 3) {
         if (use_big) rc = launch<3, 4, 2, 2, 4>(p, st);
-        else if (Cout > 64) rc = launch<3, 2, 2, 2, 2>(p, st);
-        else if (Cout > 32) rc = launch<3, 1, 2, 4, 1>(p, st);
+        else if (bn == 128) rc = launch<3, 2, 2, 2, 2>(p, st);
+        else if (bn == 64) rc = launch<3, 1, 2, 4, 1>(p, st);
         else rc = launch<3, 1, 1, 4, 1>(p, st);
     } else {
         if (Cout > 64) rc = launch<1, 2, 2, 2, 2>(p, st);
