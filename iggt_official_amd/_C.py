@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -76,6 +76,9 @@ _SIGNATURES = {
     "iggt_conv2d_nhwc_f32": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                              _c_int]
                             + [_c_int] * 24 + [_c_void_p],
+    "iggt_conv2d_nhwc_f32_ws": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
+                                _c_int]
+                               + [_c_int] * 24 + [_c_void_p, _c_long, _c_void_p],
     "iggt_bilinear_ac_nhwc_f32": [_c_void_p, _c_int, _c_void_p, _c_int] + [_c_int] * 6 + [_c_void_p] * 3,
     "iggt_linear_f32": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p,
                         _c_long, _c_int, _c_int, _c_int, _c_int, _c_void_p],
@@ -440,12 +443,26 @@ def conv2d_nhwc(x, w_hi, w_lo, bias, y, *, KH, KW, stride=1, pad_y=0, pad_x=0, H
     Ho = Hout if Ho is None else Ho
     Wo = Wout if Wo is None else Wo
     assert w_hi.dtype == torch.bfloat16 and w_hi.is_contiguous() and w_hi.shape[1] == KH * KW * Cin
-    rc = load().iggt_conv2d_nhwc_f32(x.data_ptr(), ldx, w_hi.data_ptr(), _ptr(w_lo), _ptr(bias), _ptr(res),
-                                     _ptr(res2), 0 if res is None else res.shape[3], y.data_ptr(), ldy, N, Hi, Wi, Cin, Ho, Wo,
-                                     Cout, KH, KW, stride, pad_y, pad_x, Hout, Wout, osy, osx, ooy, oox, cout_phys,
-                                     ps, int(relu_in), int(relu_res), act, prec, _stream())
-    _check(rc, "iggt_conv2d_nhwc_f32")
+    ws = _conv_ws(x.device)
+    rc = load().iggt_conv2d_nhwc_f32_ws(x.data_ptr(), ldx, w_hi.data_ptr(), _ptr(w_lo), _ptr(bias), _ptr(res),
+                                        _ptr(res2), 0 if res is None else res.shape[3], y.data_ptr(), ldy, N, Hi, Wi, Cin, Ho,
+                                        Wo, Cout, KH, KW, stride, pad_y, pad_x, Hout, Wout, osy, osx, ooy, oox, cout_phys,
+                                        ps, int(relu_in), int(relu_res), act, prec, ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "iggt_conv2d_nhwc_f32_ws")
     return y
+
+
+_CONV_WS = {}
+CONV_WS_BYTES = 64 << 20
+
+
+def _conv_ws(device):
+    """Split-K scratch of iggt_conv2d_nhwc_f32_ws: one buffer per device, shared by all launches (ordered on one stream);
+    allocated on first use, i.e. in the eager warm-up that precedes any hipGraph capture."""
+    ws = _CONV_WS.get(device)
+    if ws is None:
+        ws = _CONV_WS[device] = torch.empty(CONV_WS_BYTES, dtype=torch.uint8, device=device)
+    return ws
 
 
 def bilinear_ac_nhwc(x, y, xpart=None, ypart=None):

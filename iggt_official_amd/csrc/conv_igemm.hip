@@ -54,6 +54,10 @@ struct ConvParams {
     int relu_in, relu_res, act;  // act: 0 none, 1 relu, 2 leaky 0.01, 3 gelu(erf)
     int tiles_n;
     long M;
+    // split K (SPLITK instantiation only): grid.y slices of kchunks K-chunks each write their raw partial tile to
+    // part[slice][M][Cout]; conv_splitk_finalize_kernel adds the slices in order and applies the epilogue
+    int ksplit, kchunks;
+    float* part;
 };
 
 constexpr int BK = 32;
@@ -77,9 +81,22 @@ struct ConvTile {
     static constexpr int SMEM = (2 * STAGE > EPI_ROWS * BN * 4) ? 2 * STAGE : EPI_ROWS * BN * 4;
 };
 
-template <int PREC, int WM, int WN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(const ConvParams p) {
+template <int PREC, int WM, int WN, int WAVES_M, int WAVES_N, bool SPLITK = false>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(const ConvParams pin) {
     using T = ConvTile<PREC, WM, WN, WAVES_M, WAVES_N>;
+    // SPLITK: this workgroup owns K chunks [kt_beg, kt_beg + kchunks) and writes its raw partial sums (no bias / activation
+    // / residual, plain [M][Cout] layout) to its slice of the scratch buffer -- the epilogue code below runs unchanged on a
+    // parameter block whose output side has been redirected.
+    ConvParams ploc = pin;
+    int kt_beg = 0;
+    if constexpr (SPLITK) {
+        kt_beg = blockIdx.y * pin.kchunks;
+        ploc.y = pin.part + (long)blockIdx.y * pin.M * pin.Cout;
+        ploc.ldy = pin.Cout;
+        ploc.bias = nullptr; ploc.res = nullptr; ploc.res2 = nullptr;
+        ploc.act = 0; ploc.relu_res = 0;
+    }
+    const ConvParams& p = ploc;
     constexpr int THREADS = T::THREADS, BM = T::BM, BN = T::BN;
     static_assert(BM == THREADS / 2, "A loader: two threads per tile row");
     static_assert(T::EPI_ROWS == BM || WAVES_M == 2, "two-pass epilogue: one wave row per pass");
@@ -110,11 +127,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
     const int w_row = tid >> 2, w_piece = tid & 3;  // 4 x 16 B per row
     const long Ktot = (long)p.KH * p.KW * p.Cin;
     const int chunks_per_tap = p.Cin / BK;
-    const int KT = p.KH * p.KW * chunks_per_tap;
+    const int KT_all = p.KH * p.KW * chunks_per_tap;
+    const int KT = SPLITK ? ((KT_all - kt_beg) < p.kchunks ? (KT_all - kt_beg) : p.kchunks) : KT_all;
 
     // ---- loader state: chunks are requested strictly in order, so (tap, channel offset) is tracked incrementally
     //      (no per-chunk integer division) and the tap's pixel pointer / in-bounds flag only change with the tap.
     int ld_c0 = 0, ld_ky = 0, ld_kx = 0;
+    if constexpr (SPLITK) {
+        const int tap0 = kt_beg / chunks_per_tap;
+        ld_c0 = (kt_beg - tap0 * chunks_per_tap) * BK;
+        ld_ky = tap0 / p.KW;
+        ld_kx = tap0 - ld_ky * p.KW;
+    }
     bool ld_ok = false;
     const float* ld_src = a_base;
     auto set_tap = [&]() {
@@ -133,7 +157,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
         w_ptr_hi[q] = p.w_hi + (long)r * Ktot + w_piece * 8;
         w_ptr_lo[q] = (PREC == 3) ? p.w_lo + (long)r * Ktot + w_piece * 8 : nullptr;
     }
-    int w_k = 0;  // running K offset (elements) of the weight loads
+    int w_k = kt_beg * BK;  // running K offset (elements) of the weight loads
     const float relu_floor = p.relu_in ? 0.f : -INFINITY;  // fused ReLU-on-load as one v_max (x = max(x, floor))
 
     // Two register sets: the loads of chunk kt+2 are in flight while chunk kt is multiplied and chunk kt+1 is written
@@ -418,6 +442,67 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
     }
 }
 
+// y[m][n] = act(sum_z part[z][m][n] + bias[n]) + (relu_res ? max(res, 0) : res) + res2, slices added in z order
+__global__ __launch_bounds__(256) void conv_splitk_finalize_kernel(const ConvParams p) {
+    const int C4 = p.Cout >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.M * C4) return;
+    const long m = idx / C4;
+    const int n = (int)(idx - m * C4) * 4;
+    const long slice = p.M * p.Cout;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.part + m * p.Cout + n);
+    for (int z = 1; z < p.ksplit; ++z) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p.part + z * slice + m * p.Cout + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += t[e];
+    }
+    if (p.bias) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += b[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
+        else if (p.act == 2) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+        else if (p.act == 3) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+    }
+    if (p.res) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += p.relu_res ? fmaxf(r[e], 0.f) : r[e];
+        if (p.res2) {
+            const f32x4 r2 = *reinterpret_cast<const f32x4*>(p.res2 + m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r2[e];
+        }
+    }
+    *reinterpret_cast<f32x4*>(p.y + m * p.ldy + n) = v;
+}
+
+// split-K launch of the 128 x 128 tile: ks slices of the K loop per output tile + the finalize pass
+int launch_splitk(const ConvParams& p, int ks, int kchunks, float* part, hipStream_t st) {
+    using T = ConvTile<3, 2, 2, 2, 2>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<3, 2, 2, 2, 2, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    ConvParams q = p;
+    q.tiles_n = (p.Cout + T::BN - 1) / T::BN;
+    q.ksplit = ks; q.kchunks = kchunks; q.part = part;
+    const long tiles_m = (p.M + T::BM - 1) / T::BM;
+    hipLaunchKernelGGL((conv_igemm_kernel<3, 2, 2, 2, 2, true>), dim3((unsigned)(tiles_m * q.tiles_n), (unsigned)ks),
+                       dim3(T::THREADS), T::SMEM, st, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const long n4 = p.M * (p.Cout >> 2);
+    hipLaunchKernelGGL(conv_splitk_finalize_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, q);
+    return 0;
+}
+
 template <int PREC, int WM, int WN, int WAVES_M, int WAVES_N>
 int launch(const ConvParams& p, hipStream_t st) {
     using T = ConvTile<PREC, WM, WN, WAVES_M, WAVES_N>;
@@ -443,12 +528,12 @@ int iggt_launch_conv3x3_halo(const float* x, int ldx, const void* w_hi, const vo
                              const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg, int H, int W,
                              int Cin, int Cout, int relu_in, int relu_res, int act, hipStream_t st);
 
-extern "C" int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
-                                    const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg, int Hi, int Wi,
-                                    int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_y,
-                                    int pad_x, int Hout, int Wout, int osy, int osx, int ooy, int oox,
-                                    int cout_phys, int ps, int relu_in, int relu_res, int act, int prec,
-                                    void* stream) {
+extern "C" int iggt_conv2d_nhwc_f32_ws(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
+                                       const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg, int Hi,
+                                       int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_y,
+                                       int pad_x, int Hout, int Wout, int osy, int osx, int ooy, int oox,
+                                       int cout_phys, int ps, int relu_in, int relu_res, int act, int prec,
+                                       void* ws, long ws_bytes, void* stream) {
     if (Nimg <= 0 || Cin <= 0 || (Cin % BK) != 0 || Cout <= 0 || KH <= 0 || KW <= 0) return -1;
     if ((ldx % 4) != 0 || ldx < Cin) return -2;
     if ((ldy % 4) != 0 || (res && (ldr % 4) != 0) || (cout_phys % 4) != 0 && ps > 1) return -2;
@@ -465,6 +550,7 @@ extern "C" int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, c
     p.relu_in = relu_in; p.relu_res = relu_res; p.act = act;
     p.M = (long)Nimg * Ho * Wo;
     p.tiles_n = 0;
+    p.ksplit = 1; p.kchunks = 0; p.part = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (prec == 3 && KH == 3 && KW == 3 && stride == 1 && pad_y == 1 && pad_x == 1 && ps == 1 && osy == 1 && osx == 1 &&
         ooy == 0 && oox == 0 && Ho == Hi && Wo == Wi && Hout == Hi && Wout == Wi && cout_phys == Cout) {
@@ -489,6 +575,35 @@ extern "C" int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, c
     }
     const bool use_big = big && prec == 3 && (Cout % 256) == 0 && ((p.M + 255) / 256) * (Cout / 256) >= 2L * cus;
     int rc;
+    // Few output pixels AND a long K (1024 channels x 9 taps = 288 chunks on a 19^2 / 37^2 map): every workgroup of the few
+    // tiles walks the whole K alone (~1 us per chunk: 300 us whatever the map size).  Split K over grid.y so that the
+    // (tile, slice) pairs fill the chip; the partial tiles go through a scratch buffer and a finalize pass (fixed summation
+    // order).  Plain convolutions only (no pixel shuffle / scatter).  IGGT_CONV_SPLITK=0 disables it.
+    static int splitk = -1;
+    if (splitk < 0) {
+        const char* e = getenv("IGGT_CONV_SPLITK");
+        splitk = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (splitk && prec == 3 && !use_big && ws != nullptr && ((uintptr_t)ws % 16) == 0 && ps == 1 && osy == 1 && osx == 1 &&
+        ooy == 0 && oox == 0 && Hout == Ho && Wout == Wo && cout_phys == Cout && Cout >= 128 && (Cout % 4) == 0 &&
+        (ldy % 4) == 0 && (!res || (ldr % 4) == 0)) {
+        const long tiles = ((p.M + 127) / 128) * ((Cout + 127) / 128);
+        const int KT = KH * KW * (Cin / BK);
+        if (tiles * 2 <= cus && KT >= 48) {
+            long ks = cus / tiles;
+            if (ks > KT / 16) ks = KT / 16;
+            if (ks > 16) ks = 16;
+            while (ks > 1 && ks * p.M * Cout * 4 > ws_bytes) --ks;
+            if (ks > 1) {
+                const int kchunks = (int)((KT + ks - 1) / ks);
+                ks = (KT + kchunks - 1) / kchunks;       // no empty slice
+                const int rc2 = launch_splitk(p, (int)ks, kchunks, (float*)ws, st);
+                if (rc2 != 0) return rc2;
+                IGGT_CHECK_LAUNCH();
+                return 0;
+            }
+        }
+    }
     // Few output pixels (the 19^2 / 37^2 maps of a handful of views: the demo's 3-4 images, one rank of an 8-GPU run): the
     // 128 x 128 tiling leaves most CUs idle while every workgroup walks a long K (1024 channels x 9 taps = 288 chunks).
     // Narrower column tiles (128 x 64, 128 x 32) multiply the workgroups; the activation split per MFMA they add back is
@@ -580,4 +695,15 @@ extern "C" int iggt_bilinear_ac_nhwc_f32(const float* x, int ldx, float* y, int 
     hipLaunchKernelGGL(bilinear_ac_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
+                                    const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg, int Hi, int Wi,
+                                    int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_y,
+                                    int pad_x, int Hout, int Wout, int osy, int osx, int ooy, int oox,
+                                    int cout_phys, int ps, int relu_in, int relu_res, int act, int prec,
+                                    void* stream) {
+    return iggt_conv2d_nhwc_f32_ws(x, ldx, w_hi, w_lo, bias, res, res2, ldr, y, ldy, Nimg, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW,
+                                   stride, pad_y, pad_x, Hout, Wout, osy, osx, ooy, oox, cout_phys, ps, relu_in, relu_res,
+                                   act, prec, nullptr, 0, stream);
 }

@@ -201,6 +201,15 @@ int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, const void* 
                          int pad_x, int Hout, int Wout, int osy, int osx, int ooy, int oox,
                          int cout_phys, int ps, int relu_in, int relu_res, int act, int prec,
                          void* stream);
+/* The same with a scratch buffer (16-byte aligned, used by one call at a time on a stream) that lets plain convolutions with
+ * few output tiles and a long K (1024 channels x 9 taps on the 19^2 / 37^2 maps of 3-4 views) split the K loop over
+ * several workgroups per tile; the partial tiles are added in a fixed order by a finalize pass.  ws == NULL: as above. */
+int iggt_conv2d_nhwc_f32_ws(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
+                         const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg, int Hi, int Wi,
+                         int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_y,
+                         int pad_x, int Hout, int Wout, int osy, int osx, int ooy, int oox,
+                         int cout_phys, int ps, int relu_in, int relu_res, int act, int prec,
+                         void* ws, long ws_bytes, void* stream);
 
 /* Bilinear resize with align_corners=True, NHWC fp32, optional separable additive position map
  * (xpart [Wo][C/2] for channels [0,C/2), ypart [Ho][C/2] for [C/2,C)).

@@ -58,6 +58,36 @@ def test_conv_fused_relu_residuals_and_acts():
         assert _err(y.permute(0, 3, 1, 2), fn(base))[0] < 2e-5, act
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,n,hw", [(1024, 256, 3, 1, 4, (19, 19)), (1024, 1024, 3, 2, 4, (37, 37)),
+                                                    (512, 320, 3, 1, 1, (13, 21)), (1536, 384, 1, 1, 1, (1, 4800)),
+                                                    (256, 256, 3, 1, 2, (12, 18))])
+def test_conv_split_k_small_maps(cin, cout, k, stride, n, hw):
+    """Few output tiles, long K: the launcher splits the K loop over grid.y (csrc/conv_igemm.hip launch_splitk) and a
+    finalize pass applies bias / activation / residuals.  Ragged M and Cout, K chunks not divisible by the slice count,
+    every epilogue feature; the last shape is the tracker's fc2 as a 1 x 1 convolution over 4 800 token rows."""
+    from iggt_official_amd.heads import convops as co
+
+    pad = k // 2
+    conv = nn.Conv2d(cin, cout, k, stride, pad).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(_mk(conv.weight.shape, 31, (cin * k * k) ** -0.5))
+        conv.bias.copy_(_mk(conv.bias.shape, 32, 0.1))
+    pc = co.pack_conv2d(conv)
+    x = _mk((n, hw[0], hw[1], cin), 33)
+    xd = x.permute(0, 3, 1, 2).double()
+    base = F.conv2d(F.relu(xd), conv.weight.double(), conv.bias.double(), stride, pad)
+    ho, wo = base.shape[-2:]
+    r1, r2 = _mk((n, ho, wo, cout), 34), _mk((n, ho, wo, cout), 35)
+    y = co.run(pc, x, relu_in=True, res=r1, relu_res=True, res2=r2)
+    ref = base + F.relu(r1.permute(0, 3, 1, 2).double()) + r2.permute(0, 3, 1, 2).double()
+    assert _err(y.permute(0, 3, 1, 2), ref)[0] < 2e-5
+    y = co.run(pc, x, relu_in=True, act=3)
+    assert _err(y.permute(0, 3, 1, 2), F.gelu(base))[0] < 2e-5
+    out = r1.clone()                                        # residual and output in the same buffer
+    co.run(pc, x, relu_in=True, res=out, out=out)
+    assert _err(out.permute(0, 3, 1, 2), base + r1.permute(0, 3, 1, 2).double())[0] < 2e-5
+
+
 @pytest.mark.parametrize("cin,cout,n,hw", [(256, 256, 2, (74, 74)), (256, 128, 1, (70, 100)), (64, 128, 3, (16, 50)),
                                            (512, 256, 1, (37, 74)), (128, 512, 2, (24, 48)), (32, 256, 1, (148, 148))])
 def test_conv3x3_halo_tile_kernel(cin, cout, n, hw):
