@@ -91,3 +91,44 @@ def test_view_partition_contract():
     assert [view_partition(32, 8, r) for r in (0, 7)] == [(0, 4), (28, 32)]
     with pytest.raises(ValueError):
         view_partition(30, 8, 0)
+
+
+def _worker_one(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from iggt_official_amd.dist import ViewShard
+
+        plain, forced = ViewShard(), ViewShard(force=True, kv_groups=4)
+        assert plain.world == 1 and not plain.active and plain.kv_groups == 1
+        assert forced.active and forced.kv_groups == 4       # a world of one that issues its collectives anyway
+        kv = torch.randn(7, 16)
+        assert torch.equal(forced.all_gather_kv(kv), kv)
+        out, finish = forced.all_gather_kv_begin(kv)
+        finish()
+        assert torch.equal(out, kv)
+        fm = torch.randn(3, 5, 6, 8)                         # the track head gathers its NHWC feature maps by rows
+        assert torch.equal(forced.all_gather_rows(fm), fm)
+        ret[0] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_view_shard_forced_collectives_world_of_one():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_one, args=(1, _free_port(), ret), nprocs=1, join=True)
+    assert dict(ret) == {0: "ok"}
+
+
+def test_query_points_argument_forms():
+    """reference vggt.py:59-60 / 192-193: [N, 2] -> [1, N, 2]; anything else is rejected before any computation."""
+    from iggt.models.vggt import IGGT
+
+    q = torch.zeros(5, 2)
+    assert IGGT._query(None, 1) is None
+    assert IGGT._query(q, 1).shape == (1, 5, 2)
+    assert IGGT._query(q[None].repeat(3, 1, 1), 3).shape == (3, 5, 2)
+    for bad, b in ((torch.zeros(5, 3), 1), (torch.zeros(2, 5, 2), 1), (torch.zeros(5), 1)):
+        with pytest.raises(ValueError):
+            IGGT._query(bad, b)
