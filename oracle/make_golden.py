@@ -3,7 +3,8 @@
 
 TEST INFRASTRUCTURE.  Usage:  python oracle/make_golden.py [--out DIR] [case ...]
 (default cases: every one except the BASELINE-size ones in LARGE, which take minutes to an hour of CPU time and are
-generated on request: `python oracle/make_golden.py full_s8_518_stress full_s32_518_stress`)
+generated on request: `python oracle/make_golden.py full_s8_518_stress full_s32_518_stress`; `python oracle/make_golden.py real`
+generates the four real-photograph cases of BASELINE.json configs[0])
 
 Imports /root/reference through oracle/ref_shim.py, fills the reference IGGT with the
 seeded synthetic weights of oracle/weights.py, runs the forward path exactly as
@@ -42,7 +43,18 @@ CASES = {
     # BASELINE.json configs[4]'s per-view shape: 1036^2 (74 x 74 patch grid, 5 481 tokens per view; part head valid)
     "full_s2_1036_stress": (2, 1036, 1036, "stress", 0, 9, 14, 64, 4),
 }
-LARGE = ("full_s8_518_stress", "full_s32_518_stress", "full_s2_1036_stress")
+# BASELINE.json configs[0]: REAL photographs (the reference's iggt_demo scenes, copied to tests/golden/images/ as data
+# fixtures) through the reference's OWN loader (iggt/utils/load_fn.py, torchvision.transforms.ToTensor stubbed): every other
+# case feeds iid hash noise, whose token statistics are homogeneous -- photographs have sky / texture / edges.
+#   name: (scene, loader mode, resize target (W, H) or None, weight mode, weight seed, spatial stride, token stride, channel stride)
+REAL = {
+    "real_demo1_s3_crop518_stress": ("demo1", "crop", None, "stress", 0, 7, 16, 2),      # 3 x 350 x 518 (25 x 37 grid), geometry
+    "real_demo7_s4_crop518_stress": ("demo7", "crop", None, "stress", 0, 7, 16, 2),      # 4 x 518 x 518, geometry
+    "real_demo1_s3_336x504_stress": ("demo1", "resize", (504, 336), "stress", 0, 7, 16, 2),   # demo.py:59,182-186 default size
+    "real_demo7_s4_336x504_stress": ("demo7", "resize", (504, 336), "stress", 0, 7, 16, 2),
+}
+IMAGE_DIR = os.path.join(GOLDEN_DIR, "images")
+LARGE = ("full_s8_518_stress", "full_s32_518_stress", "full_s2_1036_stress") + tuple(REAL)
 # The reference's part head evaluates `cross_attention_1` (whose result it discards, part_head.py:178-185) with an explicit
 # softmax over (4g)^2 x (4g)^2 scores per frame and head: 87 616^2 x 8 x 4 B = 245 GB at 1036^2 -- it cannot run here.
 NO_PART = ("full_s2_1036_stress",)
@@ -53,9 +65,58 @@ def schema_of(model):
     return {k: {"shape": list(v.shape), "dtype": str(v.dtype)} for k, v in sd.items()}
 
 
+def stage_demo_images(scene):
+    """Copy the reference's demo photographs of `scene` into tests/golden/images/<scene>/ (data fixtures: the GPU box has
+    no /root/reference) and return the sorted list of the copies' paths (demo.py:203-210 sorts the directory listing)."""
+    import shutil
+
+    src = os.path.join(ref_shim.REF_ROOT, "iggt_demo", scene, "images")
+    dst = os.path.join(IMAGE_DIR, scene)
+    os.makedirs(dst, exist_ok=True)
+    for f in sorted(os.listdir(src)):
+        if not os.path.exists(os.path.join(dst, f)):
+            shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
+    return [os.path.join(dst, f) for f in sorted(os.listdir(dst))]
+
+
+def reference_loader():
+    """The reference's load_and_preprocess_images (iggt/utils/load_fn.py:12-128) itself.  Its only missing import is
+    torchvision (`transforms.ToTensor`, load_fn.py:9,54): stubbed with torchvision's documented behaviour for 8-bit RGB
+    PIL images (uint8 HWC -> float CHW / 255, torchvision/transforms/functional.py to_tensor)."""
+    import types
+
+    import numpy as np
+
+    ref_shim.install()
+    if "torchvision" not in sys.modules:
+        tv, tf = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+
+        class ToTensor:
+            def __call__(self, pic):
+                a = torch.from_numpy(np.array(pic, np.uint8, copy=True))
+                return a.view(pic.size[1], pic.size[0], 3).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+
+        tf.ToTensor = ToTensor
+        tv.transforms = tf
+        sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tf
+    from iggt.utils.load_fn import load_and_preprocess_images
+
+    ref_shim.assert_reference(load_and_preprocess_images)
+    return load_and_preprocess_images
+
+
 def run_case(model, name):
-    S, H, W, mode, wseed, iseed, sstride, tstride = CASES[name][:8]
-    cstride = CASES[name][8] if len(CASES[name]) > 8 else 1
+    if name in REAL:
+        import hashlib
+
+        scene, lmode, target, mode, wseed, sstride, tstride, cstride = REAL[name]
+        paths = stage_demo_images(scene)
+        imgs = reference_loader()(paths, mode=lmode, resize_target_size=target)
+        S, _, H, W = imgs.shape
+        iseed = None
+    else:
+        S, H, W, mode, wseed, iseed, sstride, tstride = CASES[name][:8]
+        cstride = CASES[name][8] if len(CASES[name]) > 8 else 1
     schema = schema_of(model)
     t0 = time.time()
     sd = weights.fill_state_dict(schema, seed=wseed, mode=mode)
@@ -65,10 +126,18 @@ def run_case(model, name):
                for m in missing), missing
     print(f"[{name}] weights filled in {time.time() - t0:.1f}s", flush=True)
 
-    images = weights.make_images(S, H, W, seed=iseed)[None]  # [1,S,3,H,W]
+    images = (imgs if name in REAL else weights.make_images(S, H, W, seed=iseed))[None]  # [1,S,3,H,W]
     out = {"meta": dict(S=S, H=H, W=W, mode=mode, weight_seed=wseed, image_seed=iseed,
                         spatial_stride=sstride, token_stride=tstride, channel_stride=cstride,
                         torch=torch.__version__)}
+    if name in REAL:
+        # the loader's output is k / 255 exactly: keep it as bytes (digest of the whole tensor + a strided sample)
+        u8 = (imgs * 255.0).round().to(torch.uint8)
+        assert torch.equal(u8.float().div(255), imgs)
+        out["meta"].update(scene=scene, loader_mode=lmode, resize_target_size=target,
+                           files=[os.path.basename(p) for p in paths],
+                           images_sha256=hashlib.sha256(u8.numpy().tobytes()).hexdigest())
+        out["images_u8_sample"] = u8[:, :, ::sstride, ::sstride].clone()
     cap = {}
     h = model.aggregator.patch_embed.register_forward_hook(
         lambda m, i, o: cap.__setitem__("dino", o["x_norm_patchtokens"].detach().clone()))
@@ -117,6 +186,27 @@ def run_case(model, name):
         if sstride == 1:
             for k, v in ada.items():
                 out[f"adaptor_{k}"] = v.clone()
+    if name in REAL:
+        # the caller's next two steps on the reference's own outputs (demo.py:340-352): camera decode and depth unprojection
+        # by the reference functions; iggt.utils.geometry imports iggt.utils.misc / device (cv2, torch_geometric: absent)
+        # for helpers this path never calls -> inert stubs, as in oracle/make_golden_utils.py
+        import types
+
+        for mod, attrs in (("iggt.utils.misc", ("invalid_to_zeros", "invalid_to_nans")), ("iggt.utils.device", ("to_numpy",))):
+            if mod not in sys.modules:
+                st = types.ModuleType(mod)
+                for a in attrs:
+                    setattr(st, a, lambda *x, **k: (_ for _ in ()).throw(RuntimeError("stub")))
+                sys.modules[mod] = st
+        from iggt.utils.geometry import unproject_depth_map_to_point_map
+        from iggt.utils.pose_enc import pose_encoding_to_extri_intri
+
+        ref_shim.assert_reference(unproject_depth_map_to_point_map)
+        ref_shim.assert_reference(pose_encoding_to_extri_intri)
+        extri, intri = pose_encoding_to_extri_intri(pose[-1], (H, W))
+        world = torch.from_numpy(unproject_depth_map_to_point_map(depth[0], extri[0], intri[0]))   # [S,H,W,3] float64
+        out["extrinsic"], out["intrinsic"] = extri.clone(), intri.clone()
+        out["world_points_from_depth"] = world[:, ::sstride, ::sstride].float().clone()
     # whole-tensor statistics pin the un-sampled part too
     stats = {}
     for k, v in [("depth", depth), ("depth_conf", depth_conf), ("world_points", pts),
@@ -150,6 +240,8 @@ def main():
     # integer buffers (relative position indices) are structural, save their values
     ints = {k: v.clone() for k, v in model.state_dict().items() if not v.dtype.is_floating_point and v.numel() > 1}
     torch.save(ints, os.path.join(OUT_DIR, "int_buffers.pt"))
+    if argv == ["real"]:
+        argv = list(REAL)
     names = argv or [c for c in CASES if c not in LARGE]
     for n in names:
         run_case(model, n)

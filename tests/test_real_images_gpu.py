@@ -1,0 +1,136 @@
+"""BASELINE.json configs[0] through the HIP path: REAL photographs (GPU).
+
+Every other end-to-end fixture feeds iid hash noise.  White noise gives statistically homogeneous patch tokens -- the best
+case for the two devices the headline numbers lean on (mean-input compensation of the fp16 weight rounding, static softmax
+bound).  Here the reference's own demo scenes (`iggt_demo/demo1`: 3 photographs 512 x 341, `demo7`: 4 photographs 512 x 512;
+copied to tests/golden/images/ as data fixtures) go through the whole caller chain of demo.py:178-202,340-352
+
+    JPEG --load_and_preprocess_images--> [S,3,H,W] --IGGT.forward--> pose_enc / depth / points / part_feat
+         --pose_encoding_to_extri_intri--> [R|t], K --unproject_depth_map_to_point_map--> world points
+
+on HIP kernels and are compared with what the REFERENCE produced for the same files (oracle/make_golden.py `real`: the
+reference's load_fn.py with torchvision's ToTensor stubbed, its modules with the stress weights, its pose_enc.py /
+geometry.py).  Loader: bit-identical (sha256 of the bytes).  Model: the gates of tests/test_e2e_gpu.py.  The token-layer
+error is reported with and without mean-input compensation (profiles/r03_parity_report.json, keys real/...)."""
+import hashlib
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, report
+from helpers import build_gpu_model, errors
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["real_demo1_s3_crop518_stress", "real_demo7_s4_crop518_stress", "real_demo1_s3_336x504_stress",
+         "real_demo7_s4_336x504_stress"]
+GATE_L2, GATE_MAX, GATE_L2C = 1e-3, 1.5e-3, 1e-3
+
+
+@pytest.fixture(autouse=True)
+def _restore_precision():
+    from iggt_official_amd import precision
+
+    old, old_comp = precision.operand_dtype(), precision._mean_comp
+    yield
+    precision.set_operand_dtype(old)
+    precision.set_mean_compensation(old_comp)
+
+
+def _paths(m):
+    return [os.path.join(GOLDEN, "images", m["scene"], f) for f in m["files"]]
+
+
+def _load(m):
+    from iggt.utils.load_fn import load_and_preprocess_images
+
+    tgt = m["resize_target_size"]
+    return load_and_preprocess_images(_paths(m), mode=m["loader_mode"], resize_target_size=None if tgt is None else tuple(tgt))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_loader_is_bit_identical_to_the_reference_loader(case):
+    g = load_golden(case)
+    m = g["meta"]
+    images = _load(m)
+    assert images.is_cuda and images.dtype == torch.float32 and images.shape == (m["S"], 3, m["H"], m["W"])
+    u8 = (images * 255.0).round().to(torch.uint8)
+    assert torch.equal(u8.float().div(255), images)                      # every value is k / 255 exactly
+    ss = m["spatial_stride"]
+    assert torch.equal(u8[:, :, ::ss, ::ss].cpu(), g["images_u8_sample"])
+    assert hashlib.sha256(u8.cpu().numpy().tobytes()).hexdigest() == m["images_sha256"]
+
+
+def _forward(model, images):
+    cap = {}
+    h = model.aggregator.register_forward_hook(lambda mod, i, o: cap.__setitem__("tokens", o[0]))
+    pred = model(images)
+    h.remove()
+    torch.cuda.synchronize()
+    return pred, cap["tokens"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_demo_chain_matches_reference(case):
+    from iggt.utils.geometry import unproject_depth_map_to_point_map
+    from iggt.utils.pose_enc import pose_encoding_to_extri_intri
+    from iggt_official_amd import precision
+
+    g = load_golden(case)
+    m = g["meta"]
+    ss, ts, cs = m["spatial_stride"], m["token_stride"], m["channel_stride"]
+    model = build_gpu_model(m["mode"], m["weight_seed"])
+    images = _load(m)
+    precision.set_operand_dtype("f16")
+    pred, tokens = _forward(model, images)
+    res = {}
+    for li in (4, 11, 17, 23):
+        res[f"tokens_{li}"] = errors(tokens[li][:, :, ::ts, ::cs], g[f"tokens_{li}"])
+    res["pose_enc"] = errors(torch.stack(pred["pose_enc"], 0), g["pose_enc"])
+    for k in ("depth", "depth_conf", "world_points", "world_points_conf"):
+        res[k] = errors(pred[k][:, :, ::ss, ::ss], g[k])
+    if "part_feat" in g:
+        res["part_feat"] = errors(pred["part_feat"][:, :, :, ::ss, ::ss], g["part_feat"])
+    else:
+        assert "part_feat" not in pred
+    # the caller's next two steps (demo.py:340-352) on the HIP outputs
+    extri, intri = pose_encoding_to_extri_intri(pred["pose_enc"][-1], (m["H"], m["W"]))
+    world = unproject_depth_map_to_point_map(pred["depth"][0], extri[0], intri[0], as_tensor=True)
+    res["extrinsic"] = errors(extri, g["extrinsic"])
+    res["intrinsic"] = errors(intri, g["intrinsic"])
+    res["world_points_from_depth"] = errors(world[:, ::ss, ::ss], g["world_points_from_depth"])
+    # the same forward without mean-input compensation: what the compensation buys on photographs (report only)
+    precision.set_mean_compensation(False)
+    _, tok_nc = _forward(model, images)
+    nocomp = {f"tokens_{li}": errors(tok_nc[li][:, :, ::ts, ::cs], g[f"tokens_{li}"]) for li in (4, 11, 17, 23)}
+    precision.set_mean_compensation(True)
+    report(f"real/{case}", {k: dict(max=v[0], l2=v[1], l2_centered=v[2]) for k, v in res.items()})
+    report(f"real/{case}/no_mean_compensation", {k: dict(max=v[0], l2=v[1], l2_centered=v[2]) for k, v in nocomp.items()})
+    for k, v in pred.items():
+        if torch.is_tensor(v):
+            assert torch.isfinite(v).all(), k
+    for k, v in res.items():
+        assert v[1] < GATE_L2, (k, v)
+        if not k.startswith("tokens_"):
+            assert v[0] < GATE_MAX and v[2] < GATE_L2C, (k, v)
+
+
+@pytest.mark.parametrize("case", ["real_demo7_s4_crop518_stress"])
+def test_demo_chain_bf16_operands(case):
+    """The reference's own GPU arithmetic (autocast bf16, demo.py:190-195) on photographs: the bf16 gates of test_e2e_gpu.py."""
+    from iggt_official_amd import precision
+
+    g = load_golden(case)
+    m = g["meta"]
+    ss, ts, cs = m["spatial_stride"], m["token_stride"], m["channel_stride"]
+    model = build_gpu_model(m["mode"], m["weight_seed"])
+    images = _load(m)
+    precision.set_operand_dtype("bf16")
+    pred, tokens = _forward(model, images)
+    res = {f"tokens_{li}": errors(tokens[li][:, :, ::ts, ::cs], g[f"tokens_{li}"]) for li in (4, 11, 17, 23)}
+    for k in ("depth", "depth_conf", "world_points", "world_points_conf"):
+        res[k] = errors(pred[k][:, :, ::ss, ::ss], g[k])
+    report(f"real/{case}/bf16", {k: dict(max=v[0], l2=v[1], l2_centered=v[2]) for k, v in res.items()})
+    for k, v in res.items():
+        assert v[1] < 1e-2 and v[0] < 3e-2, (k, v)
