@@ -3,6 +3,7 @@
 
   python bench.py --gpus 1 --steps K --warmup W                      (single GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N ranks, RCCL)
+  python bench.py --gpus N ...                                       (no launcher: spawns the N ranks itself, same thing)
 
 Workload (BASELINE.json configs[2] / [3]): 32 synthetic views @ 518x518, end-to-end forward =
 DINOv2 backbone + 24 x (frame, global) blocks + camera head + depth head + point head, seeded synthetic
@@ -166,6 +167,55 @@ def output_check(pred, S, H, v0, v1, dev):
     return out
 
 
+def _secondary_rooflines(g_recs, c_recs):
+    """[{gemm}, {conv}]: algorithmic FLOPs / HIP-event time per kernel family, against the same dense 16-bit MFMA peak.  The
+    head convolutions compute fp32-grade products out of three bf16 MFMAs each (split-bf16): their
+    ALGORITHMIC rate is what is reported; `mfma_equivalent` is 3x that."""
+    out = []
+    by = {}
+    for ms, (name, M, N, K) in g_recs:
+        d = by.setdefault(name, [0.0, 0.0, 0, (M, N, K)])
+        d[0] += ms
+        d[1] += 2.0 * M * N * K
+        d[2] += 1
+    if by:
+        tot_ms = sum(d[0] for d in by.values())
+        tot_fl = sum(d[1] for d in by.values())
+        out.append({"kernel": "gemm_bf16_t256pp_kernel / gemm_bf16_dma_kernel (trunk Linears incl. bias / GELU / LayerScale / "
+                              "residual epilogues)", "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                    "ms_per_forward": tot_ms, "launches": sum(d[2] for d in by.values()),
+                    "per_shape": {k: {"M_N_K": list(d[3]), "launches": d[2], "ms_mean": d[0] / d[2],
+                                      "tflops": d[1] / (d[0] * 1e-3) / 1e12} for k, d in by.items()}})
+    if c_recs:
+        ms = sum(r[0] for r in c_recs)
+        fl = sum(r[1] for r in c_recs)
+        out.append({"kernel": "conv3x3_halo_kernel / conv_igemm_kernel (DPT head convolutions, split-bf16 products)",
+                    "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "mfma_equivalent_tflops": 3.0 * fl / (ms * 1e-3) / 1e12,
+                    "ms_per_forward": ms, "launches": len(c_recs)})
+    return out
+
+
+def _self_launch(n):
+    """Re-execute this script as n ranks of one node: python -m torch.distributed.run --nnodes=1 --nproc-per-node n
+    --master-addr 127.0.0.1 --master-port <free port> bench.py <the same arguments>.  stdout / stderr pass through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    rc = subprocess.call(cmd, env=env, cwd=ROOT)
+    if rc != 0:
+        raise SystemExit(rc)
+
+
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-baseline-worker":
         return _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
@@ -186,9 +236,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` typed like the N = 1 case: spawn the ranks ourselves (one process per GPU under
+        # torch.distributed.run, the launcher the driver uses) and relay rank 0's JSON line
+        return _self_launch(args.gpus)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world} of the launcher")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback for the product path)")
     # developer switch (not a product path): IGGT_BENCH_SINGLE_DEVICE=1 runs all ranks on cuda:0 over gloo, so that the
@@ -288,6 +341,37 @@ def main():
         step()
         fence()
     recs = profiling.summarize(profiling.disable("global_attn"))
+    soft = model.aggregator.static_softmax_stats() if precision.static_softmax() else None
+    # secondary legs, each ONE extra eager forward behind the timed region (the timed steps carry no extra events):
+    #   GEMMs (qkv / proj / fc1 / fc2 of the 72 blocks) and head convolutions, HIP events per launch;
+    #   the same global-attention kernel with bf16 operands (north_star's named operand type, the reference's autocast mode)
+    secondary, bf16_leg = None, None
+    orig_dt = precision.operand_dtype()
+    try:
+        if graphs:
+            model.enable_graphs(False)
+        profiling.enable("gemm"), profiling.enable("conv")
+        step()
+        fence()
+        g_recs = profiling.summarize(profiling.disable("gemm"))
+        c_recs = profiling.summarize(profiling.disable("conv"))
+        secondary = _secondary_rooflines(g_recs, c_recs)
+        if precision.operand_name() != "bf16" and os.environ.get("IGGT_BENCH_BF16_LEG", "1") != "0":
+            precision.set_operand_dtype("bf16")
+            step()
+            fence()
+            profiling.enable("global_attn")
+            step()
+            fence()
+            b_recs = profiling.summarize(profiling.disable("global_attn"))
+            if b_recs:
+                bf16_leg = sum(r[0] for r in b_recs) / len(b_recs)
+    except Exception as ex:  # noqa: BLE001  (never lose the main line to a side measurement)
+        secondary = secondary or [{"error": repr(ex)[:300]}]
+    finally:
+        for nm in ("gemm", "conv"):
+            profiling.disable(nm)
+        precision.set_operand_dtype(orig_dt)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -350,6 +434,16 @@ def main():
                                           "input: ~10 us)") if precision.static_softmax() else "one kernel launch",
                          "flops_per_launch": flops},
         }
+        if soft is not None:
+            line["static_softmax"] = dict(soft, note="query tiles of the last forward that the static-bound kernel handed to the "
+                                          "online-max pass, per block kind (include/iggt_hip.h guard)")
+        if secondary is not None:
+            line["roofline_secondary"] = secondary
+        if bf16_leg is not None:
+            line["roofline_bf16"] = {"bound": "mfma", "kernel": _C.attn_kernel_label(1, 16, Nq, Nk, "bf16", static_bound=precision.static_softmax(), with_part_ws=True)
+                                     + " (global attention, IGGT_OPERAND_DTYPE=bf16: one extra forward after the timed region)",
+                                     "achieved": flops / (bf16_leg * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": flops / (bf16_leg * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "ms_per_launch": bf16_leg}
         if check is not None:
             line["output_check"] = check
         if world == 1 and not args.no_cpu_baseline:

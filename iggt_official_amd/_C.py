@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -33,25 +33,21 @@ _SIGNATURES = {
     "iggt_flash_attn_f16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                                 _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
                                 _c_float, _c_int, _c_void_p],
-    "iggt_flash_attn_static_bf16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
-                                        _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
-                                        _c_void_p, _c_void_p, _c_int, _c_void_p, _c_long, _c_int, _c_void_p],
-    "iggt_flash_attn_static_f16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
-                                       _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
-                                       _c_void_p, _c_void_p, _c_int, _c_void_p, _c_long, _c_int, _c_void_p],
+    "iggt_flash_attn_static_bf16_d64": [_c_void_p] * 4 + [_c_int] * 4 + [_c_long] * 8
+                                      + [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "iggt_flash_attn_static_f16_d64": [_c_void_p] * 4 + [_c_int] * 4 + [_c_long] * 8
+                                      + [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "iggt_flash_attn_static_ws_bytes": [_c_int, _c_int, _c_int, _c_int],
-    "iggt_flash_attn_static_partial_bf16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
-                                                _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
-                                                _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
-    "iggt_flash_attn_static_partial_f16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
-                                               _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
-                                               _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
-    "iggt_flash_attn_static_combine_bf16_d64": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                                                _c_int, _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _c_long, _c_long,
-                                                _c_long, _c_long, _c_long, _c_void_p, _c_int, _c_int, _c_void_p],
-    "iggt_flash_attn_static_combine_f16_d64": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                                               _c_int, _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _c_long, _c_long,
-                                               _c_long, _c_long, _c_long, _c_void_p, _c_int, _c_int, _c_void_p],
+    "iggt_flash_attn_static_partial_bf16_d64": [_c_void_p] * 3 + [_c_int] * 4 + [_c_long] * 6
+                                              + [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p] * 3,
+    "iggt_flash_attn_static_partial_f16_d64": [_c_void_p] * 3 + [_c_int] * 4 + [_c_long] * 6
+                                              + [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p] * 3,
+    "iggt_flash_attn_static_combine_bf16_d64": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 4 + [_c_int] * 4 + [_c_long] * 8
+                                              + [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "iggt_flash_attn_static_combine_f16_d64": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 4 + [_c_int] * 4 + [_c_long] * 8
+                                              + [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "iggt_k_rownorm_max_bf16": [_c_void_p, _c_long, _c_int, _c_void_p, _c_void_p],
+    "iggt_k_rownorm_max_f16": [_c_void_p, _c_long, _c_int, _c_void_p, _c_void_p],
     "iggt_flash_attn_d64_kernel_name": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_char_p,
                                         _c_int],
     "iggt_layernorm_f32": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long,
@@ -232,20 +228,32 @@ LOG2E = 1.4426950408889634
 QKMAX_NUMEL = 32 + 32 * 4096   # iggt_qknorm_rope_*: 32 per-head norm maxima + scratch for the per-block partial maxima
 
 
+def new_attn_guard(device):
+    """Persistent adaptive-switch state of one static-bound attention call site (include/iggt_hip.h): int32 [4] =
+    {state (-1: never measured), flagged tiles of the last launch (-1: static kernel skipped), tiles, calls}."""
+    return torch.tensor([-1, 0, 0, 0], dtype=torch.int32, device=device)
+
+
+def _guard_ok(g):
+    assert g is None or (g.dtype == torch.int32 and g.numel() >= 4 and g.is_contiguous() and g.is_cuda)
+
+
 def flash_attn_d64_static(q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, qkmax, flags,
-                          q_rows_per_wg=0, part_ws=None):
-    """Static-bound attention (include/iggt_hip.h): q carries scale * log2(e), qkmax fp32 [>= 32] = per-head norm bounds of
-    q (0..15) and k (16..31) as written by qknorm_rope(..., q_scale, qkmax); flags int32 scratch; part_ws: optional byte
-    scratch (static_attn_ws_bytes) that lets small grids split the keys into ranges."""
-    _dev(q, k, v, o, qkmax, flags, part_ws)
+                          q_rows_per_wg=0, part_ws=None, guard=None, guard_prev=None):
+    """Static-bound attention (include/iggt_hip.h): q carries scale * log2(e), qkmax fp32 [>= 32]: entries 16..31 = per-head
+    norm bound of k as written by qknorm_rope(..., q_scale, qkmax) or k_rownorm_max; flags int32 scratch; part_ws: optional
+    byte scratch (static_attn_ws_bytes) that lets small grids split the keys into ranges; guard / guard_prev: new_attn_guard
+    tensors of this call site / of the same launch one layer earlier (None: always try the static kernel)."""
+    _dev(q, k, v, o, qkmax, flags, part_ws, guard, guard_prev)
     sfx = _h16(q, k, v, o)
     assert qkmax.dtype == torch.float32 and qkmax.numel() >= 32 and qkmax.is_contiguous()
     assert flags.dtype == torch.int32 and flags.is_contiguous()
     assert part_ws is None or (part_ws.dtype == torch.uint8 and part_ws.is_contiguous())
+    _guard_ok(guard), _guard_ok(guard_prev)
     fn = getattr(load(), f"iggt_flash_attn_static_{sfx}_d64")
     rc = fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Nq, Nk,
             q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, qkmax.data_ptr(), flags.data_ptr(), flags.numel(),
-            _ptr(part_ws), 0 if part_ws is None else part_ws.numel(), q_rows_per_wg, _stream())
+            _ptr(part_ws), 0 if part_ws is None else part_ws.numel(), q_rows_per_wg, _ptr(guard), _ptr(guard_prev), _stream())
     _check(rc, f"iggt_flash_attn_static_{sfx}_d64")
     return o
 
@@ -255,28 +263,44 @@ def static_attn_ws_bytes(B, H, Nq, Nk):
     return int(load().iggt_flash_attn_static_ws_bytes(B, H, Nq, Nk))
 
 
-def flash_attn_d64_static_partial(q, k, v, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, qkmax, o_part, l_part, slot0,
-                                  ksplit, q_rows_per_wg=0):
+def flash_attn_d64_static_partial(q, k, v, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, qkmax, o_part, l_part, c_part,
+                                  slot0, ksplit, q_rows_per_wg=0, guard=None, guard_prev=None):
     """One key segment -> partial slots [slot0, slot0 + ksplit) (include/iggt_hip.h)."""
-    _dev(q, k, v, qkmax, o_part, l_part)
+    _dev(q, k, v, qkmax, o_part, l_part, c_part, guard, guard_prev)
     sfx = _h16(q, k, v, o_part)
-    assert l_part.dtype == torch.float32 and o_part.is_contiguous() and l_part.is_contiguous()
+    assert l_part.dtype == torch.float32 and c_part.dtype == torch.float32 and l_part.shape == c_part.shape
+    assert o_part.is_contiguous() and l_part.is_contiguous() and c_part.is_contiguous()
+    _guard_ok(guard), _guard_ok(guard_prev)
     fn = getattr(load(), f"iggt_flash_attn_static_partial_{sfx}_d64")
     rc = fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
-            qkmax.data_ptr(), o_part.data_ptr(), l_part.data_ptr(), slot0, ksplit, q_rows_per_wg, _stream())
+            qkmax.data_ptr(), o_part.data_ptr(), l_part.data_ptr(), c_part.data_ptr(), slot0, ksplit, q_rows_per_wg,
+            _ptr(guard), _ptr(guard_prev), _stream())
     _check(rc, f"iggt_flash_attn_static_partial_{sfx}_d64")
 
 
-def flash_attn_d64_static_combine(o_part, l_part, nslots, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
-                                  o_bs, o_rs, flags, q_rows_per_wg=0):
+def flash_attn_d64_static_combine(o_part, l_part, c_part, nslots, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs,
+                                  v_rs, o_bs, o_rs, flags, q_rows_per_wg=0, guard=None, guard_prev=None):
     """Fold nslots partial slots into o + flagged-tile fallback over the full key set (include/iggt_hip.h)."""
-    _dev(o_part, l_part, q, k, v, o, flags)
+    _dev(o_part, l_part, c_part, q, k, v, o, flags, guard, guard_prev)
     sfx = _h16(q, k, v, o, o_part)
+    _guard_ok(guard), _guard_ok(guard_prev)
     fn = getattr(load(), f"iggt_flash_attn_static_combine_{sfx}_d64")
-    rc = fn(o_part.data_ptr(), l_part.data_ptr(), nslots, q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Nq,
-            Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, flags.data_ptr(), flags.numel(), q_rows_per_wg, _stream())
+    rc = fn(o_part.data_ptr(), l_part.data_ptr(), c_part.data_ptr(), nslots, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+            o.data_ptr(), B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, flags.data_ptr(), flags.numel(),
+            q_rows_per_wg, _ptr(guard), _ptr(guard_prev), _stream())
     _check(rc, f"iggt_flash_attn_static_combine_{sfx}_d64")
     return o
+
+
+def k_rownorm_max(k, qkmax):
+    """qkmax[16 + h] = max row norm of head h over the rows of k (16-bit [rows, 1024], row stride ok)."""
+    _dev(k, qkmax)
+    sfx = _h16(k)
+    assert k.dim() == 2 and k.shape[1] == 1024 and k.stride(1) == 1
+    assert qkmax.dtype == torch.float32 and qkmax.numel() >= QKMAX_NUMEL and qkmax.is_contiguous()
+    fn = getattr(load(), "iggt_k_rownorm_max_" + sfx)
+    _check(fn(k.data_ptr(), k.stride(0), k.shape[0], qkmax.data_ptr(), _stream()), "iggt_k_rownorm_max_" + sfx)
+    return qkmax
 
 
 def attn_kernel_label(B, H, Nq, Nk, operand_name, static_bound=False, q_rows_per_wg=0, with_part_ws=False):
@@ -457,11 +481,13 @@ CONV_WS_BYTES = 64 << 20
 
 
 def _conv_ws(device):
-    """Split-K scratch of iggt_conv2d_nhwc_f32_ws: one buffer per device, shared by all launches (ordered on one stream);
-    allocated on first use, i.e. in the eager warm-up that precedes any hipGraph capture."""
-    ws = _CONV_WS.get(device)
+    """Split-K scratch of iggt_conv2d_nhwc_f32_ws: one buffer per (device, stream).  Launches on one stream are ordered, so
+    they can share the partial-sum buffer; a second stream (another model, an eager forward beside a graph replay, a hipGraph
+    capture -- every capture runs on its own stream, graphs.py) gets its own.  Never freed: captured graphs hold the address."""
+    key = (device, _stream())
+    ws = _CONV_WS.get(key)
     if ws is None:
-        ws = _CONV_WS[device] = torch.empty(CONV_WS_BYTES, dtype=torch.uint8, device=device)
+        ws = _CONV_WS[key] = torch.empty(CONV_WS_BYTES, dtype=torch.uint8, device=device)
     return ws
 
 
@@ -520,11 +546,11 @@ _LINEAR_WS = {}
 
 
 def _linear_ws(device):
-    """Split-K scratch of iggt_linear_f32_ws: one zero-filled buffer per device, shared by all launches (they are ordered
-    on one stream); allocated on first use, i.e. in the eager warm-up that precedes any hipGraph capture."""
-    ws = _LINEAR_WS.get(device)
+    """Split-K scratch of iggt_linear_f32_ws: one zero-filled buffer per (device, stream), see _conv_ws."""
+    key = (device, _stream())
+    ws = _LINEAR_WS.get(key)
     if ws is None:
-        ws = _LINEAR_WS[device] = torch.zeros(load().iggt_linear_f32_ws_bytes(), dtype=torch.uint8, device=device)
+        ws = _LINEAR_WS[key] = torch.zeros(load().iggt_linear_f32_ws_bytes(), dtype=torch.uint8, device=device)
     return ws
 
 

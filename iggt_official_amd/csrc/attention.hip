@@ -60,7 +60,8 @@ int fill_params(AttnParams& p, const void* q, const void* k, const void* v, void
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs;
     p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.scale_log2 = 1.f; p.qtiles = 0; p.qkmax = nullptr; p.flags = nullptr; p.static_min_l = 0.f;
-    p.ksplit = 0; p.slot0 = 0; p.o_part = nullptr; p.l_part = nullptr;
+    p.ksplit = 0; p.slot0 = 0; p.o_part = nullptr; p.l_part = nullptr; p.c_part = nullptr;
+    p.guard = nullptr; p.guard_prev = nullptr; p.guard_retry = GUARD_RETRY_DEFAULT;
     return 0;
 }
 
@@ -82,7 +83,7 @@ int choose_ksplit(int B, int H, int Nq, int Nk) {
 }
 
 long part_ws_bytes(int slots, int B, int H, int Nq) {
-    return (long)slots * B * Nq * ((long)H * 64 * 2 + (long)H * 4);
+    return (long)slots * B * Nq * ((long)H * 64 * 2 + (long)H * 4 * 2);   // O rows (16 bit) + row sums + row shifts (fp32)
 }
 
 }  // namespace
@@ -104,12 +105,15 @@ static int flash_attn_h16(int fmt, const void* q, const void* k, const void* v, 
 // One pass of the static-bound kernel over a key segment into partial slots [slot0, slot0 + ksplit).
 static int flash_attn_static_partial_h16(int fmt, const void* q, const void* k, const void* v, int B, int H, int Nq, int Nk,
                                          long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
-                                         const float* qkmax, void* o_part, float* l_part, int slot0, int ksplit,
-                                         int q_rows_per_wg, void* stream) {
+                                         const float* qkmax, void* o_part, float* l_part, float* c_part, int slot0,
+                                         int ksplit, int q_rows_per_wg, const int* guard, const int* guard_prev,
+                                         void* stream) {
     AttnParams p;
     const int rc = fill_params(p, q, k, v, o_part, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, 0, 64);
     if (rc) return rc;
-    if (qkmax == nullptr || o_part == nullptr || l_part == nullptr || H > 16 || ksplit < 1 || slot0 < 0) return -5;
+    if (qkmax == nullptr || o_part == nullptr || l_part == nullptr || c_part == nullptr || H > 16 || ksplit < 1 || slot0 < 0)
+        return -5;
+    p.guard = const_cast<int*>(guard); p.guard_prev = guard_prev; p.c_part = c_part;
     const int code = q_rows_per_wg ? q_rows_per_wg : 6256;
     if (!valid_code(code)) return -3;
     const int kvm = code / 1000 - 4;
@@ -122,14 +126,16 @@ static int flash_attn_static_partial_h16(int fmt, const void* q, const void* k, 
 
 // Fold nslots partial results into o, flag the rows below the acceptance threshold and redo their tiles (online-max kernel
 // over all Nk keys).
-static int flash_attn_static_combine_h16(int fmt, const void* o_part, const float* l_part, int nslots, const void* q,
-                                         const void* k, const void* v, void* o, int B, int H, int Nq, int Nk, long q_bs,
-                                         long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs, long o_rs,
-                                         int* flags, int flags_len, int q_rows_per_wg, void* stream) {
+static int flash_attn_static_combine_h16(int fmt, const void* o_part, const float* l_part, const float* c_part, int nslots,
+                                         const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
+                                         long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs, long o_rs,
+                                         int* flags, int flags_len, int q_rows_per_wg, int* guard, const int* guard_prev,
+                                         void* stream) {
     AttnParams p;
     const int rc = fill_params(p, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs);
     if (rc) return rc;
-    if (o_part == nullptr || l_part == nullptr || flags == nullptr || nslots < 1) return -5;
+    if (o_part == nullptr || l_part == nullptr || c_part == nullptr || flags == nullptr || nslots < 1) return -5;
+    p.guard = guard; p.guard_prev = guard_prev; p.c_part = const_cast<float*>(c_part);
     const int code = q_rows_per_wg ? q_rows_per_wg : 6256;
     if (!valid_code(code)) return -3;
     const int rows = code % 1000;
@@ -141,8 +147,8 @@ static int flash_attn_static_combine_h16(int fmt, const void* o_part, const floa
     p.static_min_l = fmt == FMT_F16 ? STATIC_MIN_L_PER_KEY_F16 * (float)Nk : STATIC_MIN_L_BF16;
     iggt_launch_attn_combine(p, nslots, rows, fmt, (hipStream_t)stream);
     IGGT_CHECK_LAUNCH();
-    p.o_part = nullptr; p.l_part = nullptr;
-    iggt_launch_flash_attn_v3(p, rows, code / 1000 - 4, fmt, false, (hipStream_t)stream);   // gated on the flags
+    p.o_part = nullptr; p.l_part = nullptr; p.c_part = nullptr;
+    iggt_launch_flash_attn_v3(p, rows, code / 1000 - 4, fmt, false, (hipStream_t)stream);   // gated on the flags; updates the guard
     IGGT_CHECK_LAUNCH();
     return 0;
 }
@@ -152,7 +158,7 @@ static int flash_attn_static_combine_h16(int fmt, const void* o_part, const floa
 static int flash_attn_static_h16(int fmt, const void* q, const void* k, const void* v, void* o, int B, int H, int Nq,
                                  int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
                                  long o_rs, const float* qkmax, int* flags, int flags_len, void* part_ws, long part_ws_len,
-                                 int q_rows_per_wg, void* stream) {
+                                 int q_rows_per_wg, int* guard, const int* guard_prev, void* stream) {
     AttnParams p;
     const int rc = fill_params(p, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs);
     if (rc) return rc;
@@ -162,11 +168,12 @@ static int flash_attn_static_h16(int fmt, const void* q, const void* k, const vo
         if (ks > 1 && part_ws_bytes(ks, B, H, Nq) <= part_ws_len) {
             char* ws = (char*)part_ws;
             float* l_part = (float*)(ws + (long)ks * B * Nq * H * 64 * 2);
+            float* c_part = l_part + (long)ks * B * Nq * H;
             int r = flash_attn_static_partial_h16(fmt, q, k, v, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, qkmax, ws,
-                                                  l_part, 0, ks, 6256, stream);
+                                                  l_part, c_part, 0, ks, 6256, guard, guard_prev, stream);
             if (r) return r;
-            return flash_attn_static_combine_h16(fmt, ws, l_part, ks, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs,
-                                                 v_rs, o_bs, o_rs, flags, flags_len, 6256, stream);
+            return flash_attn_static_combine_h16(fmt, ws, l_part, c_part, ks, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs,
+                                                 v_bs, v_rs, o_bs, o_rs, flags, flags_len, 6256, guard, guard_prev, stream);
         }
     }
     const int code = pick_tile(B, H, Nq, q_rows_per_wg);
@@ -176,7 +183,7 @@ static int flash_attn_static_h16(int fmt, const void* q, const void* k, const vo
     if (nwork > flags_len) return -6;
     const hipError_t e = hipMemsetAsync(flags, 0, nwork * sizeof(int), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    p.qkmax = qkmax; p.flags = flags;
+    p.qkmax = qkmax; p.flags = flags; p.guard = guard; p.guard_prev = guard_prev;
     p.static_min_l = fmt == FMT_F16 ? STATIC_MIN_L_PER_KEY_F16 * (float)Nk : STATIC_MIN_L_BF16;
     iggt_launch_flash_attn_v3(p, rows, code / 1000 - 4, fmt, true, (hipStream_t)stream);
     IGGT_CHECK_LAUNCH();
@@ -206,50 +213,56 @@ extern "C" int iggt_flash_attn_static_bf16_d64(const void* q, const void* k, con
                                    int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
                                    long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
                                    int* flags, int flags_len, void* part_ws, long part_ws_bytes_len, int q_rows_per_wg,
-                                   void* stream) {
+                                   int* guard, const int* guard_prev, void* stream) {
     return flash_attn_static_h16(FMT_BF16, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
-                                 qkmax, flags, flags_len, part_ws, part_ws_bytes_len, q_rows_per_wg, stream);
+                                 qkmax, flags, flags_len, part_ws, part_ws_bytes_len, q_rows_per_wg, guard, guard_prev, stream);
 }
 
 extern "C" int iggt_flash_attn_static_partial_bf16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq,
                                            int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
-                                           const float* qkmax, void* o_part, float* l_part, int slot0, int ksplit,
-                                           int q_rows_per_wg, void* stream) {
+                                           const float* qkmax, void* o_part, float* l_part, float* c_part, int slot0,
+                                           int ksplit, int q_rows_per_wg, const int* guard, const int* guard_prev,
+                                           void* stream) {
     return flash_attn_static_partial_h16(FMT_BF16, q, k, v, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, qkmax, o_part,
-                                         l_part, slot0, ksplit, q_rows_per_wg, stream);
+                                         l_part, c_part, slot0, ksplit, q_rows_per_wg, guard, guard_prev, stream);
 }
 
-extern "C" int iggt_flash_attn_static_combine_bf16_d64(const void* o_part, const float* l_part, int nslots, const void* q,
-                                           const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
-                                           long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
-                                           long o_rs, int* flags, int flags_len, int q_rows_per_wg, void* stream) {
-    return flash_attn_static_combine_h16(FMT_BF16, o_part, l_part, nslots, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs,
-                                         v_bs, v_rs, o_bs, o_rs, flags, flags_len, q_rows_per_wg, stream);
+extern "C" int iggt_flash_attn_static_combine_bf16_d64(const void* o_part, const float* l_part, const float* c_part,
+                                           int nslots, const void* q, const void* k, const void* v, void* o, int B, int H,
+                                           int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
+                                           long o_bs, long o_rs, int* flags, int flags_len, int q_rows_per_wg, int* guard,
+                                           const int* guard_prev, void* stream) {
+    return flash_attn_static_combine_h16(FMT_BF16, o_part, l_part, c_part, nslots, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs,
+                                         k_rs, v_bs, v_rs, o_bs, o_rs, flags, flags_len, q_rows_per_wg, guard, guard_prev,
+                                         stream);
 }
 
 extern "C" int iggt_flash_attn_static_f16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
                                    int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
                                    long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
                                    int* flags, int flags_len, void* part_ws, long part_ws_bytes_len, int q_rows_per_wg,
-                                   void* stream) {
+                                   int* guard, const int* guard_prev, void* stream) {
     return flash_attn_static_h16(FMT_F16, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
-                                 qkmax, flags, flags_len, part_ws, part_ws_bytes_len, q_rows_per_wg, stream);
+                                 qkmax, flags, flags_len, part_ws, part_ws_bytes_len, q_rows_per_wg, guard, guard_prev, stream);
 }
 
 extern "C" int iggt_flash_attn_static_partial_f16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq,
                                            int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
-                                           const float* qkmax, void* o_part, float* l_part, int slot0, int ksplit,
-                                           int q_rows_per_wg, void* stream) {
+                                           const float* qkmax, void* o_part, float* l_part, float* c_part, int slot0,
+                                           int ksplit, int q_rows_per_wg, const int* guard, const int* guard_prev,
+                                           void* stream) {
     return flash_attn_static_partial_h16(FMT_F16, q, k, v, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, qkmax, o_part,
-                                         l_part, slot0, ksplit, q_rows_per_wg, stream);
+                                         l_part, c_part, slot0, ksplit, q_rows_per_wg, guard, guard_prev, stream);
 }
 
-extern "C" int iggt_flash_attn_static_combine_f16_d64(const void* o_part, const float* l_part, int nslots, const void* q,
-                                           const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
-                                           long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
-                                           long o_rs, int* flags, int flags_len, int q_rows_per_wg, void* stream) {
-    return flash_attn_static_combine_h16(FMT_F16, o_part, l_part, nslots, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs,
-                                         v_bs, v_rs, o_bs, o_rs, flags, flags_len, q_rows_per_wg, stream);
+extern "C" int iggt_flash_attn_static_combine_f16_d64(const void* o_part, const float* l_part, const float* c_part,
+                                           int nslots, const void* q, const void* k, const void* v, void* o, int B, int H,
+                                           int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
+                                           long o_bs, long o_rs, int* flags, int flags_len, int q_rows_per_wg, int* guard,
+                                           const int* guard_prev, void* stream) {
+    return flash_attn_static_combine_h16(FMT_F16, o_part, l_part, c_part, nslots, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs,
+                                         k_rs, v_bs, v_rs, o_bs, o_rs, flags, flags_len, q_rows_per_wg, guard, guard_prev,
+                                         stream);
 }
 
 // Name of the kernel instantiation the dispatcher launches for a shape (reports / bench.py: the roofline entry must name

@@ -24,7 +24,26 @@ struct AttnParams {
     int ksplit, slot0;
     bf16_t* o_part;
     float* l_part;
+    // per-row shift each partial was computed under, [slots][B][H][Nq] fp32 like l_part: segments launched with different key
+    // bounds (a rank's own keys before the gather has landed, the gathered keys after) still combine exactly
+    float* c_part;
+    // adaptive switch (static bound only).  guard[0] > 0: the static kernel flags every tile and returns at once -- this call
+    // runs the online-max kernel only; guard[0] == 0: static bound; guard[0] < 0: never measured -> inherit the verdict of
+    // guard_prev (the same kind of block one layer earlier).  The gated online-max pass updates the word from the number of
+    // flagged tiles (attention_v3.hip guard_update): more than 1/8 flagged -> the next guard_retry calls skip the static
+    // kernel.  guard[1] / [2] / [3] = flagged tiles / tiles / calls of the last launch (reports).  nullptr: always static.
+    int* guard;
+    const int* guard_prev;
+    int guard_retry;
 };
+constexpr int GUARD_RETRY_DEFAULT = 16;
+// resolve the guard word(s) to "skip the static-bound kernel in this call"
+IGGT_DEVINL bool guard_skips(const int* guard, const int* guard_prev) {
+    if (guard == nullptr) return false;
+    int g = guard[0];
+    if (g < 0) g = (guard_prev != nullptr && guard_prev[0] > 0) ? 1 : 0;
+    return g > 0;
+}
 
 constexpr int KV_TILE = 64;
 constexpr int K_BYTES = KV_TILE * 128;  // 8 KiB

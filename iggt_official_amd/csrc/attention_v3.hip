@@ -61,6 +61,32 @@ constexpr bool PIN_DEFAULT = false;
 constexpr bool PIN_DEFAULT = true;
 #endif
 
+// Adaptive switch, evaluated by workgroup 0 of the gated online-max pass (it runs right behind the static-bound kernel or
+// the combine kernel on the same stream, so the flags are final and nobody reads the guard word any more in this call):
+// count the flagged tiles and decide what the NEXT call of this block does (attention_common.h AttnParams::guard).
+IGGT_DEVINL void guard_update(const AttnParams& p, int nwork, char* smem) {
+    int n = 0;
+    for (int i = threadIdx.x; i < nwork; i += 256) n += p.flags[i] != 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    int* red = reinterpret_cast<int*>(smem);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        n = red[0] + red[1] + red[2] + red[3];
+        const int g0 = p.guard[0];
+        const bool skipped = guard_skips(p.guard, p.guard_prev);
+        int g;
+        if (skipped) g = (g0 < 0 ? p.guard_retry : g0) - 1;           // this call ran the online-max kernel only: count down
+        else g = ((long)n * 8 > (long)nwork) ? p.guard_retry : 0;     // > 1/8 of the tiles flagged: static + redo loses
+        p.guard[0] = g;
+        p.guard[1] = skipped ? -1 : n;
+        p.guard[2] = nwork;
+        p.guard[3] = p.guard[3] + 1;
+    }
+    __syncthreads();   // smem is reused by the K / V staging below
+}
+
 // PART (static bound only): the workgroup covers ONE of p.ksplit equal ranges of the key macro tiles and writes a partial
 // result -- O_s / l_s as a 16-bit row and l_s in fp32 -- that attn_combine_kernel folds: with the static bound every range
 // uses the same shift, so partial sums simply add (no running-max bookkeeping between ranges).  Used (a) to balance small
@@ -77,7 +103,18 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     const int work = xcd_remap(blockIdx.x, gridDim.x);
     if constexpr (!STATIC) {
         // fallback pass behind the static-bound kernel: only the flagged query tiles are recomputed
-        if (p.flags != nullptr && p.flags[work] == 0) return;
+        if (p.flags != nullptr) {
+            if (p.guard != nullptr && blockIdx.x == 0) guard_update(p, (int)gridDim.x, smem);
+            if (p.flags[work] == 0) return;
+        }
+    } else {
+        // adaptive switch: a block whose tiles kept failing the acceptance test goes straight to the online-max kernel
+        if (guard_skips(p.guard, p.guard_prev)) {
+            if constexpr (!PART) {
+                if (tid == 0) p.flags[work] = 1;
+            }
+            return;
+        }
     }
     const int qt = work % p.qtiles;
     int bh = work / p.qtiles, ks = 0;
@@ -161,8 +198,31 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     const float c = p.scale_log2;
     // static bound: the (negated) shift enters through the accumulator input of the first QK^T MFMA of a score block
     f32x16 cinit;
+    float shift = 0.f;
     if constexpr (STATIC) {
-        const float shift = p.qkmax[h] * p.qkmax[16 + h] * 1.00002f + 1e-3f - (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
+        // PER-ROW bound: a lane owns one query column of the swapped score block, so the shift may depend on the lane's
+        // query: s_ij <= |q^_i| max_j |k^_j|.  The norm is taken from the very fragments the MFMAs consume (this lane holds
+        // half of the row, lane ^ 32 the other half).  The two query blocks of a lane (rows r and r + 32) share one C-operand
+        // vector -- a second one would cost 16 more VGPRs in a kernel that sits at the 256-register limit of two waves per
+        // SIMD -- so the lane uses the larger of its two norms.  Rows with a small |q^| (most rows, when a few outlier tokens
+        // dominate max_i |q^_i|) no longer inherit the outliers' shift.
+        float n2 = 0.f;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float a2 = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const u32x4 w = __builtin_bit_cast(u32x4, qf[qb][kc]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = h2_lo<FMT>(w[e]), hi = h2_hi<FMT>(w[e]);
+                    a2 += lo * lo + hi * hi;
+                }
+            }
+            a2 += __shfl_xor(a2, 32, 64);
+            n2 = fmaxf(n2, a2);
+        }
+        shift = sqrtf(n2) * p.qkmax[16 + h] * 1.00002f + 1e-3f - (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
 #pragma unroll
         for (int r = 0; r < 16; ++r) cinit[r] = -shift;
     } else {
@@ -335,7 +395,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
             if constexpr (PART) {   // partial slot (slot0 + ks): dense [slot][B][Nq][H * 64] rows, l as [slot][B][H][Nq]
                 const long slot = p.slot0 + ks;
                 dst = p.o_part + ((slot * p.B + b) * p.Nq + qr) * (long)(p.H * 64) + h * 64 + 4 * fhalf;
-                if (fhalf == 0) p.l_part[((slot * p.B + b) * p.H + h) * (long)p.Nq + qr] = l;
+                if (fhalf == 0) {
+                    const long li = ((slot * p.B + b) * p.H + h) * (long)p.Nq + qr;
+                    p.l_part[li] = l;
+                    p.c_part[li] = shift;
+                }
             }
 #pragma unroll
             for (int dh = 0; dh < 2; ++dh)
@@ -360,11 +424,19 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnParams p, i
     const long row = blockIdx.x;                  // (b, query row)
     const int b = (int)(row / p.Nq), qr = (int)(row - (long)b * p.Nq);
     const int C = p.H * 64;
+    if (guard_skips(p.guard, p.guard_prev)) {     // the partial launches returned at once: hand every tile to the online-max pass
+        if (threadIdx.x < p.H) p.flags[((long)b * p.H + threadIdx.x) * p.qtiles + qr / tile_rows] = 1;
+        return;
+    }
     for (int c = threadIdx.x * 4; c < C; c += 256 * 4) {
         const int h = c >> 6;
         float L = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+        // segments may have been computed under different shifts (different key bounds): weights l_s 2^(shift_s - shift_max)
+        float cmax = -INFINITY;
+        for (int s = 0; s < nslots; ++s) cmax = fmaxf(cmax, p.c_part[(((long)s * p.B + b) * p.H + h) * (long)p.Nq + qr]);
         for (int s = 0; s < nslots; ++s) {
-            const float l = p.l_part[(((long)s * p.B + b) * p.H + h) * (long)p.Nq + qr];
+            const long li = (((long)s * p.B + b) * p.H + h) * (long)p.Nq + qr;
+            const float l = p.l_part[li] * __builtin_amdgcn_exp2f(p.c_part[li] - cmax);
             const u32x2 w = *reinterpret_cast<const u32x2*>(p.o_part + (((long)s * p.B + b) * p.Nq + qr) * (long)C + c);
             L += l;
             acc[0] += l * h2_lo<FMT>(w[0]); acc[1] += l * h2_hi<FMT>(w[0]);

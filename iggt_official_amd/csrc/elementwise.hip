@@ -235,9 +235,9 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
 
 // qkmax[s] = max over blocks of the per-block maxima written by qknorm_rope_kernel (s = q|k * 16 + head); one workgroup
 // per slot, the slot's partial maxima are contiguous.
-__global__ __launch_bounds__(256) void qkmax_reduce_kernel(float* qkmax, int nblocks) {
+__global__ __launch_bounds__(256) void qkmax_reduce_kernel(float* qkmax, int nblocks, int slot0) {
     __shared__ float sm[4];
-    const int s = blockIdx.x;
+    const int s = slot0 + blockIdx.x;
     float m = 0.f;
     for (int b = threadIdx.x; b < nblocks; b += 256) m = fmaxf(m, qkmax[32 + (long)s * QK_MAX_BLOCKS + b]);
 #pragma unroll
@@ -245,6 +245,33 @@ __global__ __launch_bounds__(256) void qkmax_reduce_kernel(float* qkmax, int nbl
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) qkmax[s] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+// Largest Euclidean norm per head over the rows of a 16-bit [rows][16 * 64] key matrix -> qkmax[16 + h] (the k half of the
+// static softmax bound; entries 0..15 are left alone).  For keys that did not come out of this rank's qknorm_rope_kernel:
+// the gathered K rows of a view-sharded run (layers/blocks.py) -- the bound has to cover every rank's keys, and measuring
+// it (one pass over K at the HBM rate, ~20 us for 44 k rows) is far tighter than any data-independent bound.
+// Two rows per iteration and block; thread -> (row parity, head, 8-element slice), reduced like qknorm_rope_kernel.
+template <int FMT>
+__global__ __launch_bounds__(256) void krownorm_kernel(const bf16_t* k, long ld, int rows, float* qkmax) {
+    const int tid = threadIdx.x;
+    const int sub = tid >> 7, head = (tid >> 3) & 15, j = tid & 7;
+    float nmax2 = 0.f;
+    for (long r = (long)blockIdx.x * 2 + sub; r < rows; r += (long)gridDim.x * 2) {
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(k + r * ld + head * 64 + j * 8);
+        float n2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = h2_lo<FMT>(raw[e]), b2 = h2_hi<FMT>(raw[e]);
+            n2 += a * a + b2 * b2;
+        }
+        n2 += __shfl_xor(n2, 1, 64); n2 += __shfl_xor(n2, 2, 64); n2 += __shfl_xor(n2, 4, 64);
+        nmax2 = fmaxf(nmax2, n2);
+    }
+    __shared__ float sm[2][16];
+    if (j == 0) sm[sub][head] = nmax2;
+    __syncthreads();
+    if (tid < 16) qkmax[32 + (long)(16 + tid) * QK_MAX_BLOCKS + blockIdx.x] = sqrtf(fmaxf(sm[0][tid], sm[1][tid]));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -601,7 +628,7 @@ static int qknorm_rope_h16(int fmt, const void* qkv, long ld_in, void* q_out, lo
     else hipLaunchKernelGGL(qknorm_rope_kernel<FMT_BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
     if (qkmax != nullptr) {
-        hipLaunchKernelGGL(qkmax_reduce_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, qkmax, grid);
+        hipLaunchKernelGGL(qkmax_reduce_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, qkmax, grid, 0);
         IGGT_CHECK_LAUNCH();
     }
     return 0;
@@ -623,6 +650,23 @@ extern "C" int iggt_qknorm_rope_f16(const void* qkv, long ld_in, void* q_out, lo
                                     long v_group_stride, float q_scale, float* qkmax, void* stream) {
     return qknorm_rope_h16(FMT_F16, qkv, ld_in, q_out, ldq, k_out, ldk, v_out, ldv, qw, qb, kw, kb, cos_t, sin_t, T, P,
                            gw, patch_start, eps, heads_per_group, k_group_stride, v_group_stride, q_scale, qkmax, stream);
+}
+
+static int k_rownorm_max(int fmt, const void* k, long ldk, int rows, float* qkmax, void* stream) {
+    if (k == nullptr || qkmax == nullptr || rows <= 0 || (ldk % 8) || ((uintptr_t)k % 16)) return -1;
+    const int grid = rows / 2 + 1 < 2048 ? rows / 2 + 1 : 2048;
+    if (fmt == FMT_F16) hipLaunchKernelGGL(krownorm_kernel<FMT_F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)k, ldk, rows, qkmax);
+    else hipLaunchKernelGGL(krownorm_kernel<FMT_BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)k, ldk, rows, qkmax);
+    IGGT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(qkmax_reduce_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, qkmax, grid, 16);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int iggt_k_rownorm_max_bf16(const void* k, long ldk, int rows, float* qkmax, void* stream) {
+    return k_rownorm_max(FMT_BF16, k, ldk, rows, qkmax, stream);
+}
+extern "C" int iggt_k_rownorm_max_f16(const void* k, long ldk, int rows, float* qkmax, void* stream) {
+    return k_rownorm_max(FMT_F16, k, ldk, rows, qkmax, stream);
 }
 
 extern "C" int iggt_im2row_patch14(const float* img, void* out, int out_f16, int S, int H, int W, int Kpad,

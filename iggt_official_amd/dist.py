@@ -74,6 +74,10 @@ class ViewShard:
             n *= s
         cur = self._bufs.get(name)
         if cur is None or cur.numel() < n or cur.dtype != like.dtype or cur.device != like.device:
+            if cur is not None:
+                from . import graphs
+
+                graphs.buffers_changed()    # captured graph segments (and their eager steps) point into the old buffer
             cur = torch.empty(n, dtype=like.dtype, device=like.device)
             self._bufs[name] = cur
         return cur[:n].view(*shape)

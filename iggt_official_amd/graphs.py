@@ -19,6 +19,23 @@ from typing import Callable, List, Tuple
 
 import torch
 
+# A captured graph holds RAW POINTERS into buffers it does not own: the block engine's workspaces (layers/blocks.py
+# Workspace), the K/V gather buffers (dist.py ViewShard), the 16-bit weight packs of every module.  Each of those owners bumps
+# this counter whenever it frees / replaces a buffer (`buffers_changed()`), every cache entry remembers the value at which it
+# was captured, and `GraphCache.run` re-captures an entry whose value is stale instead of replaying into memory the allocator
+# may have handed to someone else (sequence that used to corrupt silently: capture shape A, capture the larger shape B -- the
+# workspaces grow --, replay A; or operand format f16 -> bf16 -> f16, which re-packs every weight).
+_ALLOC_GENERATION = [0]
+
+
+def buffers_changed() -> None:
+    """Called by every owner of device buffers that graphs may point into, when it reallocates or drops one."""
+    _ALLOC_GENERATION[0] += 1
+
+
+def alloc_generation() -> int:
+    return _ALLOC_GENERATION[0]
+
 
 class SegmentedGraph:
     """Capture `fn(ctl)` as a sequence of hipGraph segments separated by the eager steps `fn` requests via ctl.eager()."""
@@ -96,23 +113,32 @@ class SegmentedGraph:
 
 
 class GraphCache:
-    """Per-model cache: input signature -> (static input buffer, SegmentedGraph)."""
+    """Per-model cache: input signature -> (static input buffer, SegmentedGraph, allocation generation at capture)."""
 
     def __init__(self):
         self._graphs = {}
+        self.captures = 0    # number of captures so far (tests / reports)
 
     def reset(self):
         self._graphs.clear()
 
     def run(self, key, images: torch.Tensor, forward: Callable[[torch.Tensor, SegmentedGraph], object]):
         entry = self._graphs.get(key)
+        if entry is not None and entry[2] != alloc_generation():
+            # some buffer this graph may point into was reallocated since the capture: every entry of that age is unsafe
+            for k in [k for k, e in self._graphs.items() if e[2] != alloc_generation()]:
+                del self._graphs[k]
+            entry = None
         if entry is None:
             static_in = images.clone()
             forward(static_in, None)                      # eager warm-up: weight packs, workspaces, RCCL set-up
             forward(static_in, None)
             g = SegmentedGraph()
             g.capture(lambda ctl: forward(static_in, ctl))
-            entry = self._graphs[key] = (static_in, g)
-        static_in, g = entry
+            self.captures += 1
+            # the warm-up (and only the warm-up: a capture that reallocated would have pointed into freed memory already)
+            # may have grown workspaces; entries captured earlier notice through their older generation
+            entry = self._graphs[key] = (static_in, g, alloc_generation())
+        static_in, g, _ = entry
         static_in.copy_(images)
         return g.replay()

@@ -10,7 +10,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from .. import _C
+from .. import _C, graphs, profiling
 
 PREC = 3  # split-bf16 (fp32-grade) by default: the reference runs the heads in fp32 (vggt.py:189)
 
@@ -97,6 +97,8 @@ class PackCache:
         ver = tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
         hit = self._d.get(key)
         if hit is None or hit[0] != ver:
+            if hit is not None:
+                graphs.buffers_changed()    # the old pack is freed here; captured graphs hold its address
             self._d[key] = (ver, build())
         return self._d[key][1]
 
@@ -119,10 +121,12 @@ def run(pc: PackedConv, x: torch.Tensor, *, out: Optional[torch.Tensor] = None, 
         c = pc.cout_phys if ldy is None else ldy
         out = (torch.zeros if (ldy and ldy != pc.cout_phys) else torch.empty)(
             N, Hout, Wout, c, dtype=torch.float32, device=x.device)
-    _C.conv2d_nhwc(x, pc.w_hi, pc.w_lo, pc.bias, out, KH=pc.KH, KW=pc.KW, stride=pc.stride, pad_y=pc.pad_y,
-                   pad_x=pc.pad_x, Ho=Ho, Wo=Wo, res=res, res2=res2, relu_in=relu_in, relu_res=relu_res, act=act,
-                   prec=PREC if prec is None else prec, Cin=pc.Cin, Cout=pc.Cout, cout_phys=pc.cout_phys, ps=pc.ps,
-                   osy=pc.osy, osx=pc.osx, ooy=pc.ooy, oox=pc.oox)
+    # bench.py's secondary roofline leg: algorithmic FLOPs of this convolution = 2 * output pixels * Cout * taps * Cin
+    with profiling.region("conv", 2.0 * N * Ho * Wo * pc.Cout * pc.KH * pc.KW * pc.Cin):
+        _C.conv2d_nhwc(x, pc.w_hi, pc.w_lo, pc.bias, out, KH=pc.KH, KW=pc.KW, stride=pc.stride, pad_y=pc.pad_y,
+                       pad_x=pc.pad_x, Ho=Ho, Wo=Wo, res=res, res2=res2, relu_in=relu_in, relu_res=relu_res, act=act,
+                       prec=PREC if prec is None else prec, Cin=pc.Cin, Cout=pc.Cout, cout_phys=pc.cout_phys, ps=pc.ps,
+                       osy=pc.osy, osx=pc.osx, ooy=pc.ooy, oox=pc.oox)
     return out
 
 

@@ -23,20 +23,25 @@ from typing import List
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
-from .. import _C, precision
+from .. import _C, graphs, precision
 from ..layers.blocks import Workspace, compensated_bias
 from . import convops as co
-from .head_act import inverse_log_transform
 from .utils import pos_embed_map, pos_embed_rows
 
 
 def custom_interpolate(x, size=None, scale_factor=None, mode="bilinear", align_corners=True):
-    """NCHW torch version kept for API parity (reference dpt_head.py:484-509)."""
+    """Reference dpt_head.py:484-509 (NCHW in, NCHW out) on the HIP resize kernel (csrc/dpt_tail.hip
+    bilinear_ac_nhwc_kernel).  The reference only ever calls it as bilinear / align_corners=True; anything else raises --
+    there is no torch fallback in the product."""
+    if mode != "bilinear" or not align_corners:
+        raise _C.HipExtensionError("custom_interpolate: only bilinear, align_corners=True is built (the reference's use)")
+    if x.dim() != 4 or not x.is_cuda:
+        raise _C.HipExtensionError("custom_interpolate expects a [N, C, H, W] tensor on the GPU (no CPU fallback)")
     if size is None:
         size = (int(x.shape[-2] * scale_factor), int(x.shape[-1] * scale_factor))
-    return F.interpolate(x, size=size, mode=mode, align_corners=align_corners)
+    nhwc = x.detach().float().permute(0, 2, 3, 1).contiguous()
+    return co.resize(nhwc, tuple(int(v) for v in size)).permute(0, 3, 1, 2)
 
 
 class ResidualConvUnit(nn.Module):
@@ -120,6 +125,8 @@ class TokenProjector:
         dt = precision.operand_dtype()
         key = (w.data_ptr(), w._version, dt, precision.mean_compensation())
         if self._pk.get(idx, (None,))[0] != key:
+            if idx in self._pk:
+                graphs.buffers_changed()    # old pack freed: captured graphs hold its address
             w2 = w.detach().reshape(w.shape[0], -1).float()
             dw = (w2 - w2.to(dt).float()).to(dt).contiguous() if precision.mean_compensation() else None
             self._pk[idx] = (key, w2.to(dt).contiguous(), conv.bias.detach().float().contiguous(), dw)
@@ -265,38 +272,13 @@ class DPTHead(nn.Module):
                                        c2[2].bias.detach().float().contiguous(), self.activation,
                                        self.conf_activation)
         else:
-            out = F.linear(out, c2[2].weight.view(c2[2].out_channels, -1), c2[2].bias)
-            preds, conf = self._activate(out)
+            raise _C.HipExtensionError(
+                f"DPTHead tail: the fused 1x1 convolution + activate_head kernel covers 32 -> 2..8 channels with activation in "
+                f"{sorted(_C.HEAD_ACT)} / {sorted(_C.CONF_ACT)}; got {c2[2].in_channels} -> {c2[2].out_channels}, "
+                f"{self.activation!r} / {self.conf_activation!r} (no torch fallback)")
         preds = preds.reshape(1, S, *preds.shape[1:])
         conf = conf.reshape(1, S, *conf.shape[1:])
         return (preds, conf, side) if self.use_point_feat else (preds, conf)
-
-    def _activate(self, fmap):
-        """activate_head (reference head_act.py:61-125) on an NHWC map."""
-        xyz, conf = fmap[..., :-1], fmap[..., -1]
-        if self.activation == "inv_log":
-            pts = inverse_log_transform(xyz)
-        elif self.activation == "exp":
-            pts = torch.exp(xyz)
-        elif self.activation == "relu":
-            pts = F.relu(xyz)
-        elif self.activation == "linear":
-            pts = xyz
-        elif self.activation == "norm":
-            pts = xyz / xyz.norm(dim=-1, keepdim=True)
-        elif self.activation == "sigmoid":
-            pts = torch.sigmoid(xyz)
-        else:
-            raise ValueError(f"Unknown activation: {self.activation}")
-        if self.conf_activation == "expp1":
-            c = 1 + conf.exp()
-        elif self.conf_activation == "expp0":
-            c = conf.exp()
-        elif self.conf_activation == "sigmoid":
-            c = torch.sigmoid(conf)
-        else:
-            raise ValueError(f"Unknown conf_activation: {self.conf_activation}")
-        return pts.contiguous(), c.contiguous()
 
     def scratch_forward(self, features: List[torch.Tensor]):
         """reference dpt_head.py:286-316 on NHWC maps -> (output_conv1 map, (out2, out3, out4))."""

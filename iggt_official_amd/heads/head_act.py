@@ -1,4 +1,6 @@
-"""Output activations (reference iggt/heads/head_act.py:11-125)."""
+"""Output activations (reference iggt/heads/head_act.py:11-125): the module-level API of the reference, kept for callers that
+import it.  NOT on the product's forward path -- DPTHead / CameraHead apply their activations inside HIP kernels
+(csrc/dpt_tail.hip, csrc/elementwise.hip head_tail_kernel, csrc/smallops.hip pose_update_kernel)."""
 import torch
 import torch.nn.functional as F
 

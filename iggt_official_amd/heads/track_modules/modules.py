@@ -17,7 +17,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ... import _C
+from ... import _C, graphs
 from .. import convops as co
 
 HEAD_SLOT = 64
@@ -42,6 +42,8 @@ class _PackCache:
         sig = tuple((p.data_ptr(), p._version) for p in params)
         ent = self._d.get(key)
         if ent is None or ent[0] != sig:
+            if ent is not None:
+                graphs.buffers_changed()    # (the tracker runs eagerly, but its packs share the allocator with graphed buffers)
             ent = (sig, make())
             self._d[key] = ent
         return ent[1]

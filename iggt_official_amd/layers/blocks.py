@@ -17,7 +17,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from .. import _C, precision, profiling
+from .. import _C, graphs, precision, profiling
 
 
 class LayerScale(nn.Module):
@@ -82,6 +82,8 @@ class Workspace:
             n *= s
         cur = self._bufs.get(name)
         if cur is None or cur.numel() < n or cur.dtype != dtype or cur.device != device:
+            if cur is not None:
+                graphs.buffers_changed()    # a captured graph may still point into the buffer that is dropped here
             cur = torch.empty(n, dtype=dtype, device=device)
             self._bufs[name] = cur
         return cur[:n].view(*shape)
@@ -150,6 +152,8 @@ class Block(nn.Module):
         dt = precision.operand_dtype()
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (dt, precision.mean_compensation())
         if self._packed_key != key:
+            if self._packed is not None:
+                graphs.buffers_changed()    # the old packs are freed below; captured graphs hold their addresses
             dev = ps[0].device
             for nm, w_ in zip(("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"), ps):
                 precision.check_operand_range(nm + ".weight", w_, dt)
@@ -172,17 +176,16 @@ class Block(nn.Module):
             if self.attn.qk_norm:
                 self._packed.update(qw=f32(self.attn.q_norm.weight), qb=f32(self.attn.q_norm.bias),
                                     kw=f32(self.attn.k_norm.weight), kb=f32(self.attn.k_norm.bias))
-                # data-independent bound of |k| for the static-bound softmax when K comes from other ranks:
-                # |LayerNorm(x) * w + b| <= sqrt(d) * max|w| + |b|; RoPE is a rotation; 2^-8 covers the 16-bit rounding
-                kw_, kb_ = self._packed["kw"], self._packed["kb"]
-                bound = (kw_.abs().max() * (self.attn.head_dim ** 0.5) + kb_.norm()) * (1.0 + 2.0 ** -8)
-                self._packed["k_bound"] = bound.reshape(1).expand(16).contiguous()
+                # adaptive switch of the static-bound attention (include/iggt_hip.h): persistent per call site, reset with the
+                # packs (new weights -> new score statistics)
+                self._packed["guard"] = _C.new_attn_guard(dev)
             self._packed_key = key
         return self._packed
 
     # ------------------------------------------------------------------------------------------
     def forward_inplace(self, x2d: torch.Tensor, ws: Workspace, *, batch: int, tokens: int,
-                        rope_geom: Optional[dict] = None, kv_gather=None, q_rows_per_wg: int = 0):
+                        rope_geom: Optional[dict] = None, kv_gather=None, q_rows_per_wg: int = 0,
+                        guard_prev: Optional[torch.Tensor] = None):
         """Run the block in place on x2d [T, C] fp32 (T = batch * tokens rows; attention is computed
         independently per `batch` group of `tokens` rows).
 
@@ -190,6 +193,8 @@ class Block(nn.Module):
         has q/k-norm + RoPE (aggregator blocks); None for the DINOv2 blocks.
         kv_gather: multi-GPU global attention: a dist.ViewShard (K/V all-gather pipelined over head groups when its
         kv_groups > 1) or a callable(kv_local [T, 2C]) -> kv_all [T_all, 2C]; None on a single GPU.
+        guard_prev: adaptive-switch word of the same kind of block one layer earlier (`attn_guard()`), consulted only while
+        this block has never been measured.
         """
         if x2d.dtype != torch.float32 or x2d.dim() != 2 or x2d.stride(1) != 1:
             raise _C.HipExtensionError("Block.forward_inplace expects a row-major fp32 [T, C] matrix")
@@ -208,7 +213,9 @@ class Block(nn.Module):
 
         sat = precision.debug_saturation()
         _C.layernorm(x2d, pk["n1w"], pk["n1b"], xn, self.norm1.eps)
-        _C.gemm_h16(xn, pk["w_qkv"], qkv, bias=compensated_bias(ws, xn, pk["dw_qkv"], pk["b_qkv"]))
+        b_ = compensated_bias(ws, xn, pk["dw_qkv"], pk["b_qkv"])
+        with profiling.region("gemm", ("qkv", T, 3 * C, C)):       # bench.py's secondary roofline leg: (name, M, N, K)
+            _C.gemm_h16(xn, pk["w_qkv"], qkv, bias=b_)
         if sat:
             precision.count_saturation("norm1", xn)
             precision.count_saturation("qkv", qkv)
@@ -221,6 +228,9 @@ class Block(nn.Module):
                   and getattr(kv_gather, "kv_groups", 1) <= 1)
         qkmax = ws.get("qkmax", (_C.QKMAX_NUMEL,), torch.float32, dev) if static else None
         sk = dict(q_scale=self.attn.scale * _C.LOG2E, qkmax=qkmax) if static else {}
+        guard = pk["guard"] if (static and precision.static_guard()) else None
+        if guard is None:
+            guard_prev = None
         if self.attn.qk_norm:
             assert rope_geom is not None
             qk_args = (pk["qw"], pk["qb"], pk["kw"], pk["kb"], rope_geom["cos"], rope_geom["sin"], T, rope_geom["P"],
@@ -241,15 +251,15 @@ class Block(nn.Module):
                 gather = kv_gather.all_gather_kv if hasattr(kv_gather, "all_gather_kv") else kv_gather
                 kv_local = ws.get("kv_local", (T, 2 * C), dt, dev)
                 _C.qknorm_rope(qkv, qkv, kv_local, kv_local[:, C:], *qk_args, **sk)
-                if static:   # keys of the other ranks: the data-independent bound instead of this rank's maximum
-                    qkmax[16:32].copy_(pk["k_bound"])
                 assert batch == 1
                 if static and q_rows_per_wg == 0 and hasattr(kv_gather, "all_gather_kv_begin") and kv_gather.active \
                         and precision.gather_overlap():
-                    overlapped = self._attend_overlapped(qkv, kv_local, kv_gather, qkmax, ao, ws, T, H, C)
+                    overlapped = self._attend_overlapped(qkv, kv_local, kv_gather, qkmax, ao, ws, T, H, C, guard, guard_prev)
                 else:
                     kv_all = gather(kv_local)
                     k_src, v_src, kv_rs, Nk, k_bs = kv_all, kv_all[:, C:], 2 * C, kv_all.shape[0], 0
+                    if static:   # the key bound has to cover every rank's keys: measured on the gathered rows
+                        _C.k_rownorm_max(kv_all[:, :C], qkmax)
         elif kv_gather is not None:
             raise _C.HipExtensionError("kv_gather needs a q/k-norm block")
         if overlapped:
@@ -262,7 +272,7 @@ class Block(nn.Module):
                     part_ws = ws.get("attn_part", (nws,), torch.uint8, dev) if nws else None
                     _C.flash_attn_d64_static(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
                                              tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,
-                                             qkmax, flags, q_rows_per_wg, part_ws)
+                                             qkmax, flags, q_rows_per_wg, part_ws, guard, guard_prev)
                 else:
                     _C.flash_attn_d64(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
                                       tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,
@@ -288,43 +298,57 @@ class Block(nn.Module):
                     main.wait_event(kv_gather.event(g))
         if sat:
             precision.count_saturation("attn_out", ao)
-        _C.gemm_h16(ao, pk["w_proj"], x2d, bias=compensated_bias(ws, ao, pk["dw_proj"], pk["b_proj"]), gamma=pk["g1"],
-                    accumulate=True)
+        b_ = compensated_bias(ws, ao, pk["dw_proj"], pk["b_proj"])
+        with profiling.region("gemm", ("proj", T, C, C)):
+            _C.gemm_h16(ao, pk["w_proj"], x2d, bias=b_, gamma=pk["g1"], accumulate=True)
         _C.layernorm(x2d, pk["n2w"], pk["n2b"], xn, self.norm2.eps)
-        _C.gemm_h16(xn, pk["w_fc1"], hid, bias=compensated_bias(ws, xn, pk["dw_fc1"], pk["b_fc1"]), act=1)
+        b_ = compensated_bias(ws, xn, pk["dw_fc1"], pk["b_fc1"])
+        with profiling.region("gemm", ("fc1", T, hid.shape[1], C)):
+            _C.gemm_h16(xn, pk["w_fc1"], hid, bias=b_, act=1)
         if sat:
             precision.count_saturation("norm2", xn)
             precision.count_saturation("mlp_hidden", hid)
-        _C.gemm_h16(hid, pk["w_fc2"], x2d, bias=compensated_bias(ws, hid, pk["dw_fc2"], pk["b_fc2"]), gamma=pk["g2"],
-                    accumulate=True)
+        b_ = compensated_bias(ws, hid, pk["dw_fc2"], pk["b_fc2"])
+        with profiling.region("gemm", ("fc2", T, C, hid.shape[1])):
+            _C.gemm_h16(hid, pk["w_fc2"], x2d, bias=b_, gamma=pk["g2"], accumulate=True)
         return x2d
 
-    def _attend_overlapped(self, qkv, kv_local, shard, qkmax, ao, ws, T, H, C):
+    def _attend_overlapped(self, qkv, kv_local, shard, qkmax, ao, ws, T, H, C, guard=None, guard_prev=None):
         """Multi-GPU global attention with the K/V all-gather hidden behind the attention over this rank's own keys.
-        Under the static softmax bound partial results over disjoint key sets simply add (csrc/attention_v3.hip), so the
-        keys are processed as segments: own keys (from kv_local, while the gather is in flight) -> slot 0; the ranks before
-        and after this one (from the gathered buffer) -> one slot per rank; one combine kernel folds the `world` slots and
-        runs the flagged-tile fallback over all keys."""
+        Under the static softmax bound partial results over disjoint key sets combine by a re-weighting that depends only on
+        the shifts they were computed under (csrc/attention_v3.hip attn_combine_kernel), so the keys are processed as
+        segments: own keys (from kv_local, while the gather is in flight; key bound = this rank's measured maximum) -> slot 0;
+        the ranks before and after this one (from the gathered buffer; key bound = the maximum MEASURED over the gathered
+        rows, one HBM pass) -> one slot per rank; one combine kernel folds the `world` slots and runs the flagged-tile fallback
+        over all keys."""
         W, r = shard.world, shard.rank
         dt, dev = qkv.dtype, qkv.device
         o_part = ws.get("attn_opart", (W, 1, T, C), dt, dev)
         l_part = ws.get("attn_lpart", (W, 1, H, T), torch.float32, dev)
+        c_part = ws.get("attn_cpart", (W, 1, H, T), torch.float32, dev)
         flags = ws.get("attn_flags", (H * ((T + 127) // 128),), torch.int32, dev)
+        qkmax_all = ws.get("qkmax_all", (_C.QKMAX_NUMEL,), torch.float32, dev)
+        g = dict(guard=guard, guard_prev=guard_prev)
         with profiling.region("global_attn", (1, T, W * T)):
             kv_all, finish = shard.all_gather_kv_begin(kv_local)
             _C.flash_attn_d64_static_partial(qkv, kv_local, kv_local[:, C:], 1, H, T, T, 0, 3 * C, 0, 2 * C, 0, 2 * C, qkmax,
-                                             o_part, l_part, 0, 1)
+                                             o_part, l_part, c_part, 0, 1, **g)
             finish()
+            _C.k_rownorm_max(kv_all[:, :C], qkmax_all)
             slot = 1
             for first, n in ((0, r), (r + 1, W - 1 - r)):      # ranks before / after this one
                 if n > 0:
                     seg = kv_all[first * T:(first + n) * T]
                     _C.flash_attn_d64_static_partial(qkv, seg, seg[:, C:], 1, H, T, n * T, 0, 3 * C, 0, 2 * C, 0, 2 * C,
-                                                     qkmax, o_part, l_part, slot, n)
+                                                     qkmax_all, o_part, l_part, c_part, slot, n, **g)
                     slot += n
-            _C.flash_attn_d64_static_combine(o_part, l_part, W, qkv, kv_all, kv_all[:, C:], ao, 1, H, T, W * T, 0, 3 * C, 0,
-                                             2 * C, 0, 2 * C, 0, C, flags)
+            _C.flash_attn_d64_static_combine(o_part, l_part, c_part, W, qkv, kv_all, kv_all[:, C:], ao, 1, H, T, W * T, 0,
+                                             3 * C, 0, 2 * C, 0, 2 * C, 0, C, flags, **g)
         return True
+
+    def attn_guard(self) -> Optional[torch.Tensor]:
+        """This block's adaptive-switch word (None before the first forward / for blocks without q/k-norm)."""
+        return None if self._packed is None else self._packed.get("guard")
 
     def forward(self, x: torch.Tensor, pos=None) -> torch.Tensor:
         """Reference signature (block.py:81): x [B, N, C] -> new tensor.  `pos` must be the standard

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _C, precision
+from .. import _C, graphs, precision
 from .blocks import Block, MemEffAttention, Mlp, Workspace, compensated_bias
 from .patch_embed import PatchEmbed
 
@@ -75,6 +75,8 @@ class DinoVisionTransformer(nn.Module):
         key = (H, W, self.pos_embed._version, self.pos_embed.data_ptr(), self.cls_token._version,
                None if self.register_tokens is None else self.register_tokens._version)
         if self._cache.get("pos_key") != key:
+            if "pos" in self._cache:
+                graphs.buffers_changed()    # the tables of the previous (H, W) / parameters are freed below
             pe = self.pos_embed.detach().float()
             N = pe.shape[1] - 1
             gh, gw = H // self.patch_size, W // self.patch_size
@@ -100,6 +102,8 @@ class DinoVisionTransformer(nn.Module):
         dt = precision.operand_dtype()
         key = (w.data_ptr(), w._version, dt, precision.mean_compensation())
         if self._cache.get("pw_key") != key:
+            if "pw" in self._cache:
+                graphs.buffers_changed()
             w2 = w.detach().reshape(w.shape[0], -1).float()
             wp = torch.zeros(w.shape[0], KPAD, dtype=dt, device=w.device)
             wp[:, : w2.shape[1]] = w2.to(dt)

@@ -132,15 +132,29 @@ class Aggregator(nn.Module):
             cat = torch.empty(1, S, P, 2 * C, dtype=torch.float32, device=dev) if i in keep else None
             for j, kind in enumerate(order):
                 if kind == "frame":
-                    self.frame_blocks[i].forward_inplace(x2d, self._ws, batch=S, tokens=P, rope_geom=rope_geom)
+                    self.frame_blocks[i].forward_inplace(x2d, self._ws, batch=S, tokens=P, rope_geom=rope_geom,
+                                                         guard_prev=self.frame_blocks[i - 1].attn_guard() if i else None)
                 else:
                     self.global_blocks[i].forward_inplace(x2d, self._ws, batch=1, tokens=T,
-                                                          rope_geom=rope_geom, kv_gather=kv_gather)
+                                                          rope_geom=rope_geom, kv_gather=kv_gather,
+                                                          guard_prev=self.global_blocks[i - 1].attn_guard() if i else None)
                 if cat is not None:  # [frame_out | global_out] (aggregator.py:267-270)
                     half = 0 if kind == "frame" else 1
                     cat[0, :, :, half * C:(half + 1) * C].copy_(tokens)
             out[i] = cat
         return out, psi
+
+    def static_softmax_stats(self) -> dict:
+        """Adaptive-switch words of the 48 aggregator blocks after a forward (synchronises): per kind, the number of query
+        tiles the static-bound kernel flagged for the online-max pass in the LAST launch of each block, the tile count, and the
+        blocks that skipped the static kernel altogether (include/iggt_hip.h `guard`)."""
+        out = {}
+        for kind, blocks in (("frame", self.frame_blocks), ("global", self.global_blocks)):
+            gs = [b.attn_guard() for b in blocks]
+            gs = [g.tolist() for g in gs if g is not None]
+            out[kind] = dict(blocks=len(gs), flagged_tiles=sum(max(g[1], 0) for g in gs), tiles=sum(g[2] for g in gs if g[1] >= 0),
+                             skipped_static=sum(1 for g in gs if g[1] < 0), online_only_next=sum(1 for g in gs if g[0] > 0))
+        return out
 
 
 def slice_expand_and_flatten(token_tensor, B, S):

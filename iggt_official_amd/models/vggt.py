@@ -73,8 +73,10 @@ class _Base(nn.Module, PyTorchModelHubMixin):
         if not self._graphs_on:
             return run(images)
         shard = self.aggregator.shard
+        # everything that selects WHICH kernels / collectives get captured is part of the key
         key = (tuple(images.shape), precision.operand_name(), precision.static_softmax(),
-               precision.mean_compensation(), None if shard is None else (shard.rank, shard.world))
+               precision.mean_compensation(), precision.gather_overlap(), precision.debug_saturation(), precision.static_guard(),
+               None if shard is None else (shard.rank, shard.world, shard.kv_groups, shard.force))
 
         def fwd(static_in, ctl):
             if shard is not None:
@@ -126,8 +128,13 @@ class _Base(nn.Module, PyTorchModelHubMixin):
     def _scenes(self, images, query_points):
         """B > 1 (reference vggt.py:149: images [B,S,3,H,W]): scenes are independent, so they run one after the other
         through the single-scene path and the outputs are concatenated along the batch dimension."""
-        outs = [self.forward(images[b], None if query_points is None else query_points[b:b + 1])
-                for b in range(images.shape[0])]
+        outs = []
+        for b in range(images.shape[0]):
+            o = self.forward(images[b], None if query_points is None else query_points[b:b + 1])
+            if self._graphs_on:
+                # a graphed forward returns its STATIC output buffers, which the next scene's replay overwrites
+                o = {k: ([t.clone() for t in v] if isinstance(v, (list, tuple)) else v.clone()) for k, v in o.items()}
+            outs.append(o)
         pred = {}
         for k, v in outs[0].items():
             if k == "pose_enc":

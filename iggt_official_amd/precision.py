@@ -76,6 +76,21 @@ def set_static_softmax(on: bool) -> None:
     _static_softmax = bool(on)
 
 
+# Adaptive switch of the static-bound attention: a block whose query tiles keep failing the acceptance test (more than 1/8
+# flagged) goes straight to the online-max kernel for the next 16 calls (include/iggt_hip.h, `guard`).  IGGT_STATIC_GUARD=0
+# always tries the static kernel first.
+_static_guard = os.environ.get("IGGT_STATIC_GUARD", "1") != "0"
+
+
+def static_guard() -> bool:
+    return _static_guard
+
+
+def set_static_guard(on: bool) -> None:
+    global _static_guard
+    _static_guard = bool(on)
+
+
 # Multi-GPU: hide the K/V all-gather behind the attention over a rank's own keys (layers/blocks.py _attend_overlapped; needs
 # the static softmax).  IGGT_GATHER_OVERLAP=0 restores gather -> one attention launch.
 _gather_overlap = os.environ.get("IGGT_GATHER_OVERLAP", "1") != "0"

@@ -134,7 +134,24 @@ def fill_state_dict(schema: dict, seed: int = 0, mode: str = "stress", device="c
     return out
 
 
-def make_images(S: int, H: int, W: int, seed: int = 1, device="cpu") -> torch.Tensor:
-    """Synthetic views in [0,1): smooth low-frequency pattern + hash noise (bit-identical on CPU/GPU)."""
+def make_images(S: int, H: int, W: int, seed: int = 1, device="cpu", mode: str = "noise") -> torch.Tensor:
+    """Synthetic views in [0,1), bit-identical on CPU and GPU.
+
+    mode "noise" (default; what every hash-noise fixture under tests/golden was generated with): iid hash noise per
+    pixel and channel.  White noise makes the patch tokens statistically homogeneous -- the easiest input for the
+    mean-input compensation and the static softmax bound, which is why tests/test_real_images_gpu.py runs photographs.
+    mode "blocks": piecewise-constant 16 x 16 pixel colour blocks (one hash draw per block and channel; a few dark / bright
+    regions per view) + 25 % hash noise: low-frequency structure with edges, for tests that need inhomogeneous tokens at
+    arbitrary sizes.  k / 256-grid values and one exact fp32 multiply-add each, so CPU and GPU agree bit for bit."""
     n = S * 3 * H * W
-    return hash_uniform(n, _name_seed("images", seed), device).view(S, 3, H, W)
+    noise = hash_uniform(n, _name_seed("images", seed), device).view(S, 3, H, W)
+    if mode == "noise":
+        return noise
+    if mode != "blocks":
+        raise ValueError(f"unknown image mode {mode!r}")
+    bh, bw = (H + 15) // 16, (W + 15) // 16
+    coarse = hash_uniform(S * 3 * bh * bw, _name_seed("image_blocks", seed), device).view(S, 3, bh, bw)
+    coarse = torch.floor(coarse * 256.0) * (1.0 / 256.0)                 # 8-bit levels: the blend below is exact in fp32
+    blocks = coarse.repeat_interleave(16, 2).repeat_interleave(16, 3)[:, :, :H, :W]
+    q = torch.floor(noise * 256.0) * (1.0 / 256.0)
+    return (blocks * 0.75).add_(q * 0.25)

@@ -58,49 +58,69 @@ int iggt_flash_attn_f16_d64(const void* q, const void* k, const void* v, void* o
                             int q_rows_per_wg, void* stream);
 
 /* The same attention with a STATIC softmax bound (csrc/attention_v3.hip): q must already carry scale * log2(e)
- * (iggt_qknorm_rope_* with q_scale) and qkmax[h] >= max_i |q_i|, qkmax[16 + h] >= max_j |k_j| (Euclidean norms of the
- * 16-bit head vectors; by Cauchy-Schwarz every score of head h is <= qkmax[h] * qkmax[16 + h]), so the numerators are
- * 2^(s - bound) from the first tile on: no running maximum, no rescale.  Rows whose numerators would sink into the
- * 16-bit subnormal range (row sum below a fixed threshold) get their query tile flagged in `flags` (int[flags_len],
- * scratch, >= B * H * ceil(Nq / 128) entries, zeroed here) and are recomputed by the online-max kernel in the same call, so
- * the result meets the tolerance of iggt_flash_attn_* for ANY input.  part_ws (NULL or part_ws_len >=
- * iggt_flash_attn_static_ws_bytes(..) bytes of scratch) lets a grid too small for the chip split the keys into ranges whose
- * partial results are folded by a second kernel (they simply add under a common static bound).  Same reference operation. */
+ * (iggt_qknorm_rope_* with q_scale) and qkmax[16 + h] >= max_j |k_j| (Euclidean norms of the 16-bit head vectors; entries
+ * 0..15, the q maxima, are not read any more: the kernel takes every query row's own norm from its operand fragments).  By
+ * Cauchy-Schwarz every score of query row i is <= |q_i| * qkmax[16 + h], so the numerators are 2^(s - bound_i) from the
+ * first tile on: no running maximum, no rescale.  Rows whose numerators would sink into the 16-bit subnormal range (row sum
+ * below a fixed threshold) get their query tile flagged in `flags` (int[flags_len], scratch, >= B * H * ceil(Nq / 128)
+ * entries, zeroed here) and are recomputed by the online-max kernel in the same call, so the result meets the tolerance of
+ * iggt_flash_attn_* for ANY input.  part_ws (NULL or part_ws_len >= iggt_flash_attn_static_ws_bytes(..) bytes of scratch)
+ * lets a grid too small for the chip split the keys into ranges whose partial results are folded by a second kernel.
+ * guard (NULL or int[4], persistent per call site, initialised to {-1, 0, 0, 0}) makes the launch adaptive: the gated
+ * online-max pass counts the flagged tiles and, when more than 1/8 were flagged, lets the next 16 calls skip the static
+ * kernel (flag every tile at once) before it is tried again; a call site that has never been measured (guard[0] < 0)
+ * inherits the verdict of guard_prev (NULL or the guard of the same kind of launch one layer earlier).  guard[1..3] =
+ * flagged tiles (-1: skipped) / tiles / calls of the last launch.  Worst case of a launch: ~1.05x the online-max kernel
+ * averaged over calls instead of static + online-max.  Same reference operation. */
 int iggt_flash_attn_static_bf16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
                                     int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
                                     long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
                                     int* flags, int flags_len, void* part_ws, long part_ws_len, int q_rows_per_wg,
-                                    void* stream);
+                                    int* guard, const int* guard_prev, void* stream);
 int iggt_flash_attn_static_f16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
                                    int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
                                    long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
                                    int* flags, int flags_len, void* part_ws, long part_ws_len, int q_rows_per_wg,
-                                   void* stream);
+                                   int* guard, const int* guard_prev, void* stream);
 long iggt_flash_attn_static_ws_bytes(int B, int H, int Nq, int Nk);
 
 /* The two halves of the split form, for callers that own the key segments themselves (multi-GPU: a rank's own keys while the
  * all-gather of the others is in flight, iggt_official_amd/dist.py):
  *   _partial_: static-bound pass of ALL queries over ONE key segment (k, v, Nk), cut into `ksplit` ranges -> slots
- *              [slot0, slot0 + ksplit) of o_part [slots][B][Nq][H*64] (16-bit, each row normalised by its own row sum) and
- *              l_part [slots][B][H][Nq] (fp32 row sums).  Every segment must use the SAME qkmax.
- *   _combine_: o = sum_s l_s O_s / sum_s l_s over nslots slots, then the flag / online-max fallback pass over the full key
- *              set (k, v, Nk).  q_rows_per_wg: 0 (= 6256) or the code both calls were given. */
+ *              [slot0, slot0 + ksplit) of o_part [slots][B][Nq][H*64] (16-bit, each row normalised by its own row sum),
+ *              l_part [slots][B][H][Nq] (fp32 row sums) and c_part (same shape: the shift each row was computed under).
+ *              Segments may use DIFFERENT qkmax (own keys: this rank's measured maximum; gathered keys: the maximum over
+ *              the gathered rows, iggt_k_rownorm_max_*): the combine step re-weights by 2^(shift_s - max_s shift_s).
+ *   _combine_: o = sum_s w_s O_s / sum_s w_s over nslots slots, then the flag / online-max fallback pass over the full key
+ *              set (k, v, Nk).  q_rows_per_wg: 0 (= 6256) or the code both calls were given.  guard / guard_prev as above
+ *              (the partial launches only read them). */
 int iggt_flash_attn_static_partial_bf16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq, int Nk,
                                             long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
-                                            const float* qkmax, void* o_part, float* l_part, int slot0, int ksplit,
-                                            int q_rows_per_wg, void* stream);
+                                            const float* qkmax, void* o_part, float* l_part, float* c_part, int slot0,
+                                            int ksplit, int q_rows_per_wg, const int* guard, const int* guard_prev,
+                                            void* stream);
 int iggt_flash_attn_static_partial_f16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq, int Nk,
                                            long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
-                                           const float* qkmax, void* o_part, float* l_part, int slot0, int ksplit,
-                                           int q_rows_per_wg, void* stream);
-int iggt_flash_attn_static_combine_bf16_d64(const void* o_part, const float* l_part, int nslots, const void* q,
-                                            const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
-                                            long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
-                                            long o_rs, int* flags, int flags_len, int q_rows_per_wg, void* stream);
-int iggt_flash_attn_static_combine_f16_d64(const void* o_part, const float* l_part, int nslots, const void* q,
-                                           const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
-                                           long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
-                                           long o_rs, int* flags, int flags_len, int q_rows_per_wg, void* stream);
+                                           const float* qkmax, void* o_part, float* l_part, float* c_part, int slot0,
+                                           int ksplit, int q_rows_per_wg, const int* guard, const int* guard_prev,
+                                           void* stream);
+int iggt_flash_attn_static_combine_bf16_d64(const void* o_part, const float* l_part, const float* c_part, int nslots,
+                                            const void* q, const void* k, const void* v, void* o, int B, int H, int Nq,
+                                            int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
+                                            long o_bs, long o_rs, int* flags, int flags_len, int q_rows_per_wg, int* guard,
+                                            const int* guard_prev, void* stream);
+int iggt_flash_attn_static_combine_f16_d64(const void* o_part, const float* l_part, const float* c_part, int nslots,
+                                           const void* q, const void* k, const void* v, void* o, int B, int H, int Nq,
+                                           int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
+                                           long o_bs, long o_rs, int* flags, int flags_len, int q_rows_per_wg, int* guard,
+                                           const int* guard_prev, void* stream);
+
+/* qkmax[16 + h] = largest Euclidean norm of the head-h vectors k[r][h * 64 .. h * 64 + 63] over r < rows (k: 16-bit
+ * [rows][ldk], 16 heads; qkmax: float[32 + 32 * 4096] as for iggt_qknorm_rope_*, entries 0..15 untouched): the key half of
+ * the static softmax bound for keys that were not produced by this rank's iggt_qknorm_rope_* call -- the gathered K rows of a
+ * view-sharded run (no reference counterpart: the reference has no inference parallelism). */
+int iggt_k_rownorm_max_bf16(const void* k, long ldk, int rows, float* qkmax, void* stream);
+int iggt_k_rownorm_max_f16(const void* k, long ldk, int rows, float* qkmax, void* stream);
 
 /* Writes the name of the kernel instantiation the attention dispatcher picks for a shape into buf (host only, no launch;
  * buf_len >= 96): reports must name the kernel that actually ran. */

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Static-bound softmax on score statistics that are NOT LayerNorm-of-noise: flagged-tile fraction and wall
+time of the global attention at the bench shape (N = 43 968, 16 heads, fp16 and bf16) for
+
+  noise      q, k = per-head LayerNorm of Gaussian noise (|q^| = 1.875, |k| = 8): what every hash-noise fixture produces
+  affine     trained-like q/k-norm affines: per-channel gamma log-normal (sigma = 1), drawn per head, on q and on k
+  sinks      affine + 8 "attention sink" keys with 10x the norm of the rest (they set max|k|, the bound of every row)
+  registers  affine + the 5 special-token rows of every view with 30x the query norm of the patch rows
+
+in four launch modes: online-max kernel alone (the fallback everything is measured against); static bound without the adaptive
+switch (static pass, then every flagged tile again); static bound with the switch, FIRST call of a cold call site; and its
+steady state (mean over 34 calls = two retry periods: 16 calls online-max only, 1 call static + redo, ...).
+Usage: python probes/attn_static_robustness.py > profiles/r03_attn_static_robustness.txt   (on the GPU box)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from iggt_official_amd import _C  # noqa: E402
+
+_C.load()
+H, C, P, VIEWS = 16, 1024, 1374, int(os.environ.get("VIEWS", "32"))
+T = VIEWS * P
+
+
+def make(kind, dt, seed=3):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(T, 3, H, 64, generator=g, device="cuda")
+    qk = x[:, :2]
+    qk = (qk - qk.mean(-1, keepdim=True)) / qk.std(-1, keepdim=True, unbiased=False)       # per-head LayerNorm: |.| = 8
+    if kind != "noise":
+        gam = torch.exp(torch.randn(2, H, 64, generator=g, device="cuda"))                  # log-normal, sigma = 1
+        gam = gam / gam.pow(2).mean(-1, keepdim=True).sqrt()                                 # rms 1 per head: typical |.| stays 8
+        qk = qk * gam[None]
+    x[:, :2] = qk
+    x[:, 0] *= 0.125 * _C.LOG2E * 1.3
+    if kind == "sinks":
+        idx = torch.randperm(T, generator=g, device="cuda")[:8]
+        x[idx, 1] *= 10.0
+    if kind == "registers":
+        rows = (torch.arange(VIEWS, device="cuda")[:, None] * P + torch.arange(5, device="cuda")[None]).reshape(-1)
+        x[rows, 0] *= 30.0
+    qkv = x.reshape(T, 3 * C).to(dt)
+    qkmax = torch.zeros(_C.QKMAX_NUMEL, device="cuda")
+    _C.k_rownorm_max(qkv[:, C:2 * C], qkmax)
+    return qkv, qkmax
+
+
+def timed(fn, reps):
+    torch.cuda.synchronize()
+    out = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        out.append(e0.elapsed_time(e1))
+    return out
+
+
+def main():
+    print(f"# global attention, {VIEWS} views @ 518^2: Nq = Nk = {T}, 16 heads x 64; {torch.cuda.get_device_name(0)}")
+    print(f"# {'operands':8s} {'input':10s} {'flagged tiles':>16s} {'online-max':>11s} {'static,no switch':>17s} "
+          f"{'switch: 1st call':>17s} {'switch: steady':>15s} {'steady / online':>16s}")
+    for dt, name in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+        for kind in ("noise", "affine", "sinks", "registers"):
+            qkv, qkmax = make(kind, dt)
+            o = torch.empty(T, C, dtype=dt, device="cuda")
+            flags = torch.zeros(H * ((T + 127) // 128), dtype=torch.int32, device="cuda")
+            args = (qkv, qkv[:, C:], qkv[:, 2 * C:], o, 1, H, T, T, 0, 3 * C, 0, 3 * C, 0, 3 * C, 0, C)
+
+            def online():
+                # q already carries scale * log2 e: softmax scale ln 2 in the online-max kernel's convention
+                _C.flash_attn_d64(*args, 0.6931471805599453, 0)
+
+            def static(guard=None):
+                _C.flash_attn_d64_static(*args, qkmax, flags, 0, None, guard, None)
+
+            online(), static()
+            t_on = sorted(timed(online, 7))[3]
+            t_st = sorted(timed(static, 7))[3]
+            ntiles = H * ((T + 255) // 256)
+            nflag = int(flags[:ntiles].sum())
+            guard = _C.new_attn_guard("cuda")
+            t_first = timed(lambda: static(guard), 1)[0]
+            steady = timed(lambda: static(guard), 34)
+            t_steady = sum(steady) / len(steady)
+            print(f"  {name:8s} {kind:10s} {nflag:7d} / {ntiles:5d} {t_on:9.2f}ms {t_st:15.2f}ms {t_first:15.2f}ms "
+                  f"{t_steady:13.2f}ms {t_steady / t_on:15.3f}x   guard={guard.tolist()}")
+
+
+if __name__ == "__main__":
+    main()

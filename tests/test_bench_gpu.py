@@ -52,3 +52,15 @@ def test_bench_two_rank_control_flow():
     assert d["config"]["parallelism"] == "view-shard x2"
     assert d["output_check"]["ok"] and d["output_check"]["max_l2_all_ranks"] < 1e-3
     assert "cpu_baseline" not in d            # rank 0 at N = 1 only
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset), as the driver types the N = 1 case: the script
+    re-executes itself under torch.distributed.run and rank 0's JSON line comes back on stdout."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["IGGT_BENCH_SINGLE_DEVICE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--views", "8", "--steps", "1",
+                          "--warmup", "1"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "view-shard x2" and d["output_check"]["ok"]

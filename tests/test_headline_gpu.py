@@ -106,6 +106,82 @@ def test_static_bound_global_attention_at_bench_shape(C, dtype):
         assert worst[0] < 1.5e-2 and worst[1] < 4e-3, worst
 
 
+class _FakeShard:
+    """Stands in for dist.ViewShard in Block._attend_overlapped: rank / world and a gather that is already complete."""
+
+    def __init__(self, world, rank, kv_all):
+        self.world, self.rank, self.kv_all = world, rank, kv_all
+
+    def all_gather_kv_begin(self, kv_local):
+        return self.kv_all, (lambda: None)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cfg", ["config4", "config5"])
+def test_sharded_global_attention_at_production_shapes(C, dtype, cfg):
+    """What rank r of 8 launches for ONE global attention of BASELINE.json configs[3] (32 views @ 518^2: Nq = 5 496 own rows
+    x Nk = 43 968 gathered keys) and configs[4] (64 views @ 1036^2: Nq = 43 848 x Nk = 350 784), through the product's own
+    code (layers/blocks.py Block._attend_overlapped): own keys first (slot 0, this rank's measured key bound), the key bound of
+    the gathered rows (iggt_k_rownorm_max), the ranks before / after as key ranges (one slot per rank), attn_combine_kernel
+    with the recorded shifts, gated online-max pass.  256 sampled query rows per head against an fp64 softmax over ALL keys.
+    config4 additionally in the gather -> one launch form with the dispatcher's automatic key-range count (7 ranges)."""
+    from iggt_official_amd.layers.blocks import Block, Workspace
+
+    H, Cdim, W, r = 16, 1024, 8, 3
+    T = 4 * 1374 if cfg == "config4" else 8 * 5481
+    Nk = W * T
+    g = torch.Generator(device="cuda").manual_seed(77)
+    kv_all = torch.randn(Nk, 2 * Cdim, generator=g, device="cuda", dtype=torch.float32).to(dtype)
+    # per-rank differences in the key norms (every rank normalises its own views): rank 6's keys are 15 % larger
+    kv_all[6 * T:7 * T, :Cdim] *= 1.15
+    qkv = torch.randn(T, 3 * Cdim, generator=g, device="cuda", dtype=torch.float32).to(dtype)
+    qkv[:, :Cdim] *= 0.125 * 1.4426950408889634            # |q^| ~ 1.44, |k| ~ 8: the model's LayerNorm-ed magnitudes
+    kv_local = kv_all[r * T:(r + 1) * T].clone()
+    qkv[:, Cdim:] = kv_local
+    ws = Workspace()
+    qkmax = torch.zeros(C.QKMAX_NUMEL, device="cuda")
+    C.k_rownorm_max(kv_local[:, :Cdim], qkmax)              # what qknorm_rope leaves for the rank's own keys
+    ao = torch.full((T, Cdim), float("nan"), dtype=dtype, device="cuda")
+    guard = C.new_attn_guard("cuda")
+    assert Block._attend_overlapped(None, qkv, kv_local, _FakeShard(W, r, kv_all), qkmax, ao, ws, T, H, Cdim, guard, None)
+    torch.cuda.synchronize()
+    flagged = guard.tolist()[1]
+    outs = {"overlapped": ao}
+    if cfg == "config4":
+        nws = C.static_attn_ws_bytes(1, H, T, Nk)
+        assert nws > 0                                       # 352 tiles of 256 rows for 512 slots: the keys are split
+        assert "7 key ranges" in C.attn_kernel_label(1, H, T, Nk, "f16" if dtype == torch.float16 else "bf16", True, 0, True)
+        C.k_rownorm_max(kv_all[:, :Cdim], qkmax)
+        o1 = torch.full((T, Cdim), float("nan"), dtype=dtype, device="cuda")
+        flags = torch.zeros(H * ((T + 127) // 128), dtype=torch.int32, device="cuda")
+        C.flash_attn_d64_static(qkv, kv_all, kv_all[:, Cdim:], o1, 1, H, T, Nk, 0, 3 * Cdim, 0, 2 * Cdim, 0, 2 * Cdim, 0, Cdim,
+                                qkmax, flags, 0, torch.empty(nws, dtype=torch.uint8, device="cuda"))
+        assert int(flags.sum()) == 0
+        outs["gathered_auto_split"] = o1
+    gcpu = torch.Generator(device="cpu").manual_seed(55)
+    name = "f16" if dtype == torch.float16 else "bf16"
+    for label, o in outs.items():
+        assert not torch.isnan(o.float()).any()
+        worst = (0.0, 0.0)
+        for h in range(H):
+            rows = torch.randperm(T, generator=gcpu)[:256].sort().values.cuda()
+            rows[:2] = torch.tensor([0, 1], device="cuda")
+            rows[-2:] = torch.tensor([T - 2, T - 1], device="cuda")
+            q = qkv[rows, h * 64:(h + 1) * 64].double()
+            p = torch.softmax(q @ kv_all[:, h * 64:(h + 1) * 64].double().t() * 0.6931471805599453, dim=-1)
+            ref = p @ kv_all[:, Cdim + h * 64:Cdim + (h + 1) * 64].double()
+            mx, l2 = _relerr(o[rows, h * 64:(h + 1) * 64], ref)
+            worst = (max(worst[0], mx), max(worst[1], l2))
+            del p, ref
+        report(f"headline/sharded_global_attn_{cfg}_{label}_{name}",
+               dict(max=worst[0], l2=worst[1], rows_per_head=256, Nq=T, Nk=Nk, rank=r, world=W, flagged_tiles=flagged))
+        if dtype == torch.float16:
+            assert worst[0] < 2e-3 and worst[1] < 5e-4, (label, worst)
+        else:
+            assert worst[0] < 1.5e-2 and worst[1] < 4e-3, (label, worst)
+    assert flagged == 0
+
+
 def _forward_vs_fixture(case, centered_gate=1e-3):
     from oracle import weights
 
@@ -162,6 +238,37 @@ def test_forward_32_views_518_matches_reference():
     """BASELINE.json configs[2] -- the configuration bench.py times: 32 views @ 518x518 (N_global = 43 968,
     column-mean sampling step 42, 2 752-workgroup attention grid, 32-frame head passes)."""
     _forward_vs_fixture("full_s32_518_stress")
+
+
+@pytest.mark.parametrize("case", ["full_s8_518_stress", "full_s32_518_stress"])
+def test_forward_bf16_operands_at_headline_sizes(case):
+    """north_star's named operand type and the reference's own GPU arithmetic (autocast bf16, demo.py:190-195) at 8 and 32
+    views @ 518^2: the bf16 gates of tests/test_e2e_gpu.py (that mode itself sits 7e-3 from fp32)."""
+    from iggt_official_amd import precision
+    from oracle import weights
+
+    old = precision.operand_dtype()
+    precision.set_operand_dtype("bf16")
+    try:
+        g = load_golden(case)
+        m = g["meta"]
+        model = build_gpu_model(m["mode"], m["weight_seed"])
+        images = weights.make_images(m["S"], m["H"], m["W"], seed=m["image_seed"], device="cuda")
+        cap = {}
+        h = model.aggregator.register_forward_hook(lambda mod, i, o: cap.__setitem__("tokens", o[0]))
+        pred = model(images)
+        h.remove()
+        torch.cuda.synchronize()
+        ss, ts, cs = m["spatial_stride"], m["token_stride"], m.get("channel_stride", 1)
+        res = {f"tokens_{li}": errors(cap["tokens"][li][:, :, ::ts, ::cs], g[f"tokens_{li}"]) for li in (4, 11, 17, 23)}
+        res["pose_enc"] = errors(torch.stack(pred["pose_enc"], 0), g["pose_enc"])
+        for k in ("depth", "depth_conf", "world_points", "world_points_conf"):
+            res[k] = errors(pred[k][:, :, ::ss, ::ss], g[k])
+        report(f"headline/{case}/bf16", {k: dict(max=v[0], l2=v[1], l2_centered=v[2]) for k, v in res.items()})
+        for k, v in res.items():
+            assert v[1] < 1e-2 and v[0] < 3e-2, (k, v)
+    finally:
+        precision.set_operand_dtype(old)
 
 
 def test_forward_2_views_1036_matches_reference():

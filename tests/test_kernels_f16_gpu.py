@@ -255,14 +255,27 @@ def test_flash_attn_static_key_split(C, dtype, B, H, Nq, Nk):
     n1 = (Nk // 3 // 8) * 8
     o_part = torch.full((4, B, Nq, Cdim), float("nan"), dtype=dtype, device="cuda")
     l_part = torch.full((4, B, H, Nq), float("nan"), device="cuda")
+    c_part = torch.full((4, B, H, Nq), float("nan"), device="cuda")
     kk, vv = qkv[:, Cdim:], qkv[:, 2 * Cdim:]
-    C.flash_attn_d64_static_partial(qkv, kk, vv, B, H, Nq, n1, *strides, qkmax, o_part, l_part, 0, 1)
-    C.flash_attn_d64_static_partial(qkv, kk[n1:], vv[n1:], B, H, Nq, Nk - n1, *strides, qkmax, o_part, l_part, 1, 3)
+    C.flash_attn_d64_static_partial(qkv, kk, vv, B, H, Nq, n1, *strides, qkmax, o_part, l_part, c_part, 0, 1)
+    C.flash_attn_d64_static_partial(qkv, kk[n1:], vv[n1:], B, H, Nq, Nk - n1, *strides, qkmax, o_part, l_part, c_part, 1, 3)
     o2 = torch.full((B * Nq, Cdim), float("nan"), dtype=dtype, device="cuda")
-    C.flash_attn_d64_static_combine(o_part, l_part, 4, qkv, kk, vv, o2, B, H, Nq, Nk, *strides, Nq * Cdim, Cdim, flags)
+    C.flash_attn_d64_static_combine(o_part, l_part, c_part, 4, qkv, kk, vv, o2, B, H, Nq, Nk, *strides, Nq * Cdim, Cdim, flags)
     mx, l2 = _relerr(o2, ref)
     report(f"attn_static_split_{'f16' if dtype == F16 else 'bf16'}_B{B}_H{H}_{Nq}x{Nk}", dict(max=mx, l2=l2))
     assert not torch.isnan(o2.float()).any() and mx < tol[0] and l2 < tol[1], (mx, l2)
+    # (c) the segments computed under DIFFERENT key bounds (multi-GPU: own keys under this rank's measured maximum, the
+    # gathered keys under the maximum over all ranks): the combine step re-weights by the recorded shifts
+    loose = qkmax.clone()
+    loose[16:] *= 1.7
+    o_part.fill_(float("nan")); l_part.fill_(float("nan")); c_part.fill_(float("nan"))
+    C.flash_attn_d64_static_partial(qkv, kk, vv, B, H, Nq, n1, *strides, qkmax, o_part, l_part, c_part, 0, 1)
+    C.flash_attn_d64_static_partial(qkv, kk[n1:], vv[n1:], B, H, Nq, Nk - n1, *strides, loose, o_part, l_part, c_part, 1, 3)
+    assert float((c_part[1] - c_part[0]).min()) > 0.5          # the second segment really ran under a larger shift
+    o3 = torch.full((B * Nq, Cdim), float("nan"), dtype=dtype, device="cuda")
+    C.flash_attn_d64_static_combine(o_part, l_part, c_part, 4, qkv, kk, vv, o3, B, H, Nq, Nk, *strides, Nq * Cdim, Cdim, flags)
+    mx, l2 = _relerr(o3, ref)
+    assert not torch.isnan(o3.float()).any() and mx < tol[0] and l2 < tol[1], (mx, l2)
 
 
 def test_flash_attn_static_key_split_fallback(C):
@@ -286,6 +299,106 @@ def test_flash_attn_static_key_split_fallback(C):
     ref = _attn_ref(q, k, v, 0.6931471805599453).transpose(0, 1).reshape(Nq, Cdim)
     mx, l2 = _relerr(o, ref)
     assert int(flags.sum()) > 0 and not torch.isnan(o.float()).any() and mx < 2e-3 and l2 < 5e-4, (int(flags.sum()), mx, l2)
+
+
+def test_flash_attn_static_per_row_bound(C):
+    """A few query rows with 30x the norm of the rest (register / camera tokens of a trained checkpoint): the shift is taken
+    per query row (|q_i| max|k|, from the operand fragments), so the ordinary rows keep their tight bound -- only the tiles
+    that CONTAIN an outlier row go to the online-max pass (a head-wide max|q| would send every tile there)."""
+    H, N = 4, 6000
+    Cdim = H * 64
+    qkv = _rand((N, 3 * Cdim), 211, 1.0, F16)
+    x = qkv.view(N, 3, H, 64)
+    qk = x[:, :2].float()
+    x[:, :2] = (qk / qk.norm(dim=-1, keepdim=True) * 8.0).half()
+    x[:, 0] *= 0.125 * 1.4426950408889634 * 1.3
+    outliers = [0, 1, 2, 3, 4, 1374, 1375, 2748, 5999]
+    x[outliers, 0] *= 30.0
+    tiles = {r // 256 for r in outliers}
+    o, ref, flags = _static_attn(C, qkv, 1, H, N, N, N, 6256, F16)
+    fl = flags[:-3].view(H, -1)
+    nflag = int(fl.sum())
+    report("attn_static_f16_per_row_bound", dict(flagged=nflag, tiles=int(fl.numel()), tiles_with_outliers=len(tiles) * H))
+    assert 0 < nflag <= len(tiles) * H
+    assert all(int(fl[:, t].sum()) == 0 for t in range(fl.shape[1]) if t not in tiles)
+    mx, l2 = _relerr(o, ref)
+    assert not torch.isnan(o.float()).any() and mx < 2e-3 and l2 < 5e-4, (mx, l2)
+    for r in outliers + [5, 33, 1376]:
+        assert _relerr(o[r], ref[r])[1] < 1e-3, r
+
+
+def test_flash_attn_static_guard(C):
+    """Adaptive switch: when more than 1/8 of the query tiles fail the acceptance test the call site skips the static kernel
+    for the next 16 calls (online-max kernel only), then tries it again; a call site that was never measured inherits the
+    verdict of the previous layer.  The result meets the tolerance in every state.  The losing input is an attention SINK:
+    one key with 10x the norm of the rest sets max|k| -- the bound of every row -- while almost no row scores near it."""
+    H, N = 2, 4000
+    Cdim = H * 64
+    good = _rand((N, 3 * Cdim), 233, 1.0, F16)
+    xg = good.view(N, 3, H, 64)
+    qk = xg[:, :2].float()
+    xg[:, :2] = (qk / qk.norm(dim=-1, keepdim=True) * 8.0).half()
+    xg[:, 0] *= 0.125 * 1.4426950408889634 * 1.3
+    bad = good.clone()
+    bad.view(N, 3, H, 64)[1234, 1] *= 10.0
+    ntiles = H * ((N + 255) // 256)
+    flags = torch.zeros(ntiles, dtype=torch.int32, device="cuda")
+
+    def setup(data):
+        x = data.view(N, 3, H, 64)
+        qkmax = torch.zeros(32, device="cuda")
+        qkmax[16:16 + H] = x[:, 1].float().norm(dim=-1).amax(0)
+        q, k, v = x[:, 0].transpose(0, 1), x[:, 1].transpose(0, 1), x[:, 2].transpose(0, 1)
+        return qkmax, _attn_ref(q, k, v, 0.6931471805599453).transpose(0, 1).reshape(N, Cdim)
+
+    def run(data, qkmax, g, gp=None):
+        o = torch.full((N, Cdim), float("nan"), dtype=F16, device="cuda")
+        C.flash_attn_d64_static(data, data[:, Cdim:], data[:, 2 * Cdim:], o, 1, H, N, N, 0, 3 * Cdim, 0, 3 * Cdim, 0, 3 * Cdim,
+                                0, Cdim, qkmax, flags, 6256, None, g, gp)
+        return o
+
+    def ok(o, ref):
+        mx, l2 = _relerr(o, ref)
+        assert not torch.isnan(o.float()).any() and mx < 2e-3 and l2 < 5e-4, (mx, l2)
+
+    qm_bad, ref_bad = setup(bad)
+    qm_good, ref_good = setup(good)
+    guard = C.new_attn_guard("cuda")
+    ok(run(bad, qm_bad, guard), ref_bad)
+    st = guard.tolist()
+    assert st[1] > ntiles // 8 and st[2] == ntiles and st[0] == 16 and st[3] == 1, st      # measured: static loses here
+    for i in range(16):                               # 16 calls on the online-max kernel alone
+        o = run(bad, qm_bad, guard)
+        st = guard.tolist()
+        assert st[1] == -1 and st[0] == 15 - i and int(flags.sum()) == ntiles, (i, st)
+        if i in (0, 15):
+            ok(o, ref_bad)
+    ok(run(bad, qm_bad, guard), ref_bad)              # the static kernel is tried again -- and loses again
+    st = guard.tolist()
+    assert st[1] > ntiles // 8 and st[0] == 16, st
+    # inheritance: a fresh call site behind a losing one skips at once; behind a winning one it measures itself
+    fresh = C.new_attn_guard("cuda")
+    ok(run(bad, qm_bad, fresh, guard), ref_bad)
+    assert fresh.tolist()[:2] == [15, -1]
+    winner, fresh2 = C.new_attn_guard("cuda"), C.new_attn_guard("cuda")
+    ok(run(good, qm_good, winner), ref_good)
+    assert winner.tolist()[:3] == [0, 0, ntiles]
+    ok(run(good, qm_good, fresh2, winner), ref_good)
+    assert fresh2.tolist()[:3] == [0, 0, ntiles]
+    # without a guard nothing changes: static pass, every tile redone
+    ok(run(bad, qm_bad, None), ref_bad)
+
+
+def test_k_rownorm_max(C):
+    """Largest per-head row norm of a strided 16-bit key matrix -> qkmax[16..31]; entries 0..15 stay as they were."""
+    for dtype, rows in ((F16, 5003), (torch.bfloat16, 2), (F16, 1)):
+        kv = _rand((rows, 2048), 77 + rows, 1.0, dtype)
+        kv[rows // 2, 3 * 64:4 * 64] *= 5.0
+        qkmax = torch.full((C.QKMAX_NUMEL,), -2.0, device="cuda")
+        C.k_rownorm_max(kv[:, :1024], qkmax)
+        ref = kv[:, :1024].float().view(rows, 16, 64).norm(dim=-1).amax(0)
+        assert torch.allclose(qkmax[16:32], ref, rtol=1e-6, atol=0), (qkmax[16:32], ref)
+        assert torch.all(qkmax[:16] == -2.0)
 
 
 def test_qknorm_rope_prescale_and_norm_maxima(C):
