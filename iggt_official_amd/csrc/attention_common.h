@@ -22,6 +22,11 @@ struct AttnParams {
     // key-split partial results (static bound only; ksplit == 0: one pass): workgroup (.., key range ks, ..) writes slot
     // slot0 + ks of o_part [slots][B][Nq][H*64] (16-bit, normalised by its own row sum) and l_part [slots][B][H][Nq] (fp32)
     int ksplit, slot0;
+    // segment mode (seg_len > 0): the `ksplit` ranges are the key SEGMENTS [s * seg_len, min((s + 1) * seg_len, Nk)) -- one
+    // rank's rows of the gathered K/V buffer each -- instead of equal shares of the macro tiles; segment skip_seg (the
+    // rank's own keys, already done from its local buffer while the gather was in flight; -1: none) is left out and the
+    // segments after it move up one slot, so that every rank launches the same 7-of-8-ranges grid whatever its position
+    int seg_len, skip_seg;
     bf16_t* o_part;
     float* l_part;
     // per-row shift each partial was computed under, [slots][B][H][Nq] fp32 like l_part: segments launched with different key

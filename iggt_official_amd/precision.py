@@ -57,6 +57,23 @@ def set_mean_compensation(on: bool) -> None:
     _mean_comp = bool(on)
 
 
+# Which of a block's four GEMMs get the compensation (each costs two small kernels per call): IGGT_MEAN_COMP_SITES, a comma
+# list out of qkv,proj,fc1,fc2 (default: all).  Part of the pack key of every block (layers/blocks.py).
+_comp_sites = frozenset(s for s in os.environ.get("IGGT_MEAN_COMP_SITES", "qkv,proj,fc1,fc2").split(",") if s)
+
+
+def mean_compensation_sites() -> frozenset:
+    return _comp_sites if mean_compensation() else frozenset()
+
+
+def set_mean_compensation_sites(sites) -> None:
+    global _comp_sites
+    sites = frozenset(sites)
+    if not sites <= {"qkv", "proj", "fc1", "fc2"}:
+        raise ValueError("sites out of qkv, proj, fc1, fc2")
+    _comp_sites = sites
+
+
 def operand_name() -> str:
     return "f16" if _operand == torch.float16 else "bf16"
 

@@ -83,6 +83,8 @@ int iggt_flash_attn_static_f16_d64(const void* q, const void* k, const void* v, 
                                    int* flags, int flags_len, void* part_ws, long part_ws_len, int q_rows_per_wg,
                                    int* guard, const int* guard_prev, void* stream);
 long iggt_flash_attn_static_ws_bytes(int B, int H, int Nq, int Nk);
+/* number of key ranges iggt_flash_attn_static_* would cut this shape into when given a workspace (1: one pass) */
+int iggt_flash_attn_static_ksplit(int B, int H, int Nq, int Nk);
 
 /* The two halves of the split form, for callers that own the key segments themselves (multi-GPU: a rank's own keys while the
  * all-gather of the others is in flight, iggt_official_amd/dist.py):
@@ -91,19 +93,23 @@ long iggt_flash_attn_static_ws_bytes(int B, int H, int Nq, int Nk);
  *              l_part [slots][B][H][Nq] (fp32 row sums) and c_part (same shape: the shift each row was computed under).
  *              Segments may use DIFFERENT qkmax (own keys: this rank's measured maximum; gathered keys: the maximum over
  *              the gathered rows, iggt_k_rownorm_max_*): the combine step re-weights by 2^(shift_s - max_s shift_s).
+ *              seg_len > 0 (segment mode): the ksplit = ceil(Nk / seg_len) ranges are the key segments [s * seg_len,
+ *              (s + 1) * seg_len) -- one rank's rows of the gathered buffer each; segment skip_seg (-1: none) is left out
+ *              and the later ones move up one slot: every rank of a view-sharded run launches the same (world - 1)-range
+ *              grid over the gathered buffer whatever its position.  seg_len = 0: equal shares of the key tiles.
  *   _combine_: o = sum_s w_s O_s / sum_s w_s over nslots slots, then the flag / online-max fallback pass over the full key
  *              set (k, v, Nk).  q_rows_per_wg: 0 (= 6256) or the code both calls were given.  guard / guard_prev as above
  *              (the partial launches only read them). */
 int iggt_flash_attn_static_partial_bf16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq, int Nk,
                                             long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
                                             const float* qkmax, void* o_part, float* l_part, float* c_part, int slot0,
-                                            int ksplit, int q_rows_per_wg, const int* guard, const int* guard_prev,
-                                            void* stream);
+                                            int ksplit, int seg_len, int skip_seg, int q_rows_per_wg, const int* guard,
+                                            const int* guard_prev, void* stream);
 int iggt_flash_attn_static_partial_f16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq, int Nk,
                                            long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
                                            const float* qkmax, void* o_part, float* l_part, float* c_part, int slot0,
-                                           int ksplit, int q_rows_per_wg, const int* guard, const int* guard_prev,
-                                           void* stream);
+                                           int ksplit, int seg_len, int skip_seg, int q_rows_per_wg, const int* guard,
+                                           const int* guard_prev, void* stream);
 int iggt_flash_attn_static_combine_bf16_d64(const void* o_part, const float* l_part, const float* c_part, int nslots,
                                             const void* q, const void* k, const void* v, void* o, int B, int H, int Nq,
                                             int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,

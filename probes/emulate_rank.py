@@ -12,7 +12,8 @@ SIZE = int(sys.argv[3]) if len(sys.argv) > 3 else 518
 
 
 class FakeShard:
-    rank, world, active = 0, N, True
+    # a MIDDLE rank by default: rank 0 owns view 0 and (before round 3) had the cheapest key-segment layout
+    rank, world, active = int(os.environ.get("IGGT_EMU_RANK", str(N // 2))), N, True
     kv_groups = int(os.environ.get("IGGT_KV_GROUPS", "1"))
     _streams, _events = [], []
 
@@ -33,7 +34,7 @@ class FakeShard:
         return kv.repeat(N, 1)
 
     def all_gather_kv_begin(self, kv):     # overlap path (own keys first): same bytes land, no transport to hide here
-        return kv.repeat(N, 1), (lambda: None)
+        return kv.repeat(N, 1), (lambda: None)   # (the copy runs on the compute stream: it is counted, RCCL's would overlap)
 
     def all_gather_rows(self, x):
         return x.repeat(N, *([1] * (x.dim() - 1)))

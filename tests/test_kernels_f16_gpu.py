@@ -276,6 +276,30 @@ def test_flash_attn_static_key_split(C, dtype, B, H, Nq, Nk):
     C.flash_attn_d64_static_combine(o_part, l_part, c_part, 4, qkv, kk, vv, o3, B, H, Nq, Nk, *strides, Nq * Cdim, Cdim, flags)
     mx, l2 = _relerr(o3, ref)
     assert not torch.isnan(o3.float()).any() and mx < tol[0] and l2 < tol[1], (mx, l2)
+    # (d) segment mode, as a rank of a view-sharded run launches it: the keys are W "rank segments" of seg rows (the last one
+    # ragged); this rank's own segment (index 1) goes first from a private copy, cut into 2 ranges -> slots W-1, W; then ONE
+    # launch over the whole buffer with the own segment left out -> slots 0 .. W-2
+    seg = ((Nk // 3 + 7) // 8) * 8 + 8
+    Wn = (Nk + seg - 1) // seg
+    assert Wn == 3 and Nk - 2 * seg > 0
+    nsl = Wn - 1 + 2
+    o_p = torch.full((nsl, B, Nq, Cdim), float("nan"), dtype=dtype, device="cuda")
+    l_p = torch.full((nsl, B, H, Nq), float("nan"), device="cuda")
+    c_p = torch.full((nsl, B, H, Nq), float("nan"), device="cuda")
+    own_k, own_v = kk[seg:], vv[seg:]
+    if B == 1:        # a private copy with its own row stride, like kv_local
+        own = qkv[seg:2 * seg, Cdim:].clone()
+        C.flash_attn_d64_static_partial(qkv, own, own[:, Cdim:], B, H, Nq, seg, strides[0], strides[1], 0, 2 * Cdim, 0, 2 * Cdim,
+                                        qkmax, o_p, l_p, c_p, Wn - 1, 2)
+    else:
+        C.flash_attn_d64_static_partial(qkv, own_k, own_v, B, H, Nq, seg, *strides, qkmax, o_p, l_p, c_p, Wn - 1, 2)
+    C.flash_attn_d64_static_partial(qkv, kk, vv, B, H, Nq, Nk, *strides, loose, o_p, l_p, c_p, 0, Wn, seg_len=seg, skip_seg=1)
+    o4 = torch.full((B * Nq, Cdim), float("nan"), dtype=dtype, device="cuda")
+    C.flash_attn_d64_static_combine(o_p, l_p, c_p, nsl, qkv, kk, vv, o4, B, H, Nq, Nk, *strides, Nq * Cdim, Cdim, flags)
+    mx, l2 = _relerr(o4, ref)
+    assert not torch.isnan(o4.float()).any() and mx < tol[0] and l2 < tol[1], (mx, l2)
+    with pytest.raises(C.HipExtensionError):       # segment count must match ceil(Nk / seg_len)
+        C.flash_attn_d64_static_partial(qkv, kk, vv, B, H, Nq, Nk, *strides, loose, o_p, l_p, c_p, 0, Wn + 1, seg_len=seg, skip_seg=1)
 
 
 def test_flash_attn_static_key_split_fallback(C):
