@@ -353,6 +353,20 @@ static int gemm_h16(int fmt, const void* A, long lda, const void* W, long ldw, i
     // Exception: grids of < 128 big tiles (e.g. N = 1024 with a few thousand rows: the per-rank proj / fc2 GEMMs of an
     // 8-GPU run) leave most CUs idle -- the 128^2 kernel's 4x finer grid wins there (measured 108 vs 131 us).
     const long big_tiles = (long)((M + 255) / 256) * (N / 256);
+    // IGGT_GEMM_DUO (A/B switch): 1 = the 256 x 128 two-workgroups-per-CU kernel wherever it applies
+    static int duo = -1;
+    if (duo < 0) {
+        const char* e = getenv("IGGT_GEMM_DUO");
+        duo = e ? atoi(e) : 0;
+    }
+    if (duo == 1 && M >= 512 && (N % 128) == 0 && force_small_tile() == 0) {
+        const int rc = iggt_launch_gemm_duo(p, fmt, (hipStream_t)stream);
+        if (rc == 0) {
+            IGGT_CHECK_LAUNCH();
+            return 0;
+        }
+        if (rc != -100) return rc;
+    }
     if (M >= 1024 && (N % 256) == 0 && big_tiles >= 128 && force_small_tile() == 0) {
         const int rc = iggt_launch_gemm_t256(p, fmt, (hipStream_t)stream);
         if (rc == 0) {

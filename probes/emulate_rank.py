@@ -15,6 +15,7 @@ class FakeShard:
     # a MIDDLE rank by default: rank 0 owns view 0 and (before round 3) had the cheapest key-segment layout
     rank, world, active = int(os.environ.get("IGGT_EMU_RANK", str(N // 2))), N, True
     kv_groups = int(os.environ.get("IGGT_KV_GROUPS", "1"))
+    force = False
     _streams, _events = [], []
 
     def gather_kv_groups(self, kv_local):
