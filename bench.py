@@ -229,6 +229,10 @@ def main():
     ap.add_argument("--cpu-sample-views", type=int, default=4)
     ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
                     help="replay the forward as hipGraph segments (auto: when N > 1, where the per-rank forward is host-bound)")
+    ap.add_argument("--emulate-world", type=int, default=0, metavar="W",
+                    help="developer mode, --gpus 1 only: time what ONE (middle) rank of a W-GPU run computes -- its S / W views, "
+                         "the global attention over the keys of all S views (gathers replaced by local copies, "
+                         "iggt_official_amd/dist.py EmulatedShard).  The outputs are not the model's; no output check")
     ap.add_argument("--random-init", action="store_true",
                     help="torch random-init weights and images instead of the synthetic checkpoint (no output check)")
     args = ap.parse_args()
@@ -268,7 +272,7 @@ def main():
 
     from iggt.models.vggt import IGGT
     from iggt_official_amd import _C, precision, profiling, synthetic
-    from iggt_official_amd.dist import ViewShard, view_partition
+    from iggt_official_amd.dist import EmulatedShard, ViewShard, view_partition
 
     _C.load()
     S, H = args.views, args.size
@@ -277,10 +281,16 @@ def main():
     torch.manual_seed(0)  # identical weights on every rank
     with torch.device(dev):
         model = IGGT(part_on_invalid_grid="skip").eval()
+    emu = args.emulate_world if (args.emulate_world > 1 and world == 1) else 0
+    if emu and S % emu:
+        raise SystemExit(f"--views {S} must be divisible by --emulate-world {emu}")
     if world > 1 or force_coll:
         shard = ViewShard()
         model.set_view_shard(shard)
-    v0, v1 = view_partition(S, world, rank)
+    elif emu:
+        shard = EmulatedShard(emu)
+        model.set_view_shard(shard)
+    v0, v1 = shard.local_views(S) if emu else view_partition(S, world, rank)
     if args.random_init:
         g = torch.Generator(device="cpu").manual_seed(1234)
         images = torch.rand(S, 3, H, H, generator=g)[v0:v1].to(dev)
@@ -298,7 +308,7 @@ def main():
         images = synthetic.make_images(S, H, H, seed=iseed, device=dev)[v0:v1].contiguous()
         data = "synthetic (seeded hash weights 'stress' seed 0 and hash-noise images, iggt_official_amd/synthetic.py)"
 
-    graphs = args.graphs == "on" or (args.graphs == "auto" and world > 1)
+    graphs = args.graphs == "on" or (args.graphs == "auto" and (world > 1 or emu))
     if graphs:
         model.enable_graphs(True)   # first call captures (inside the warm-up)
 
@@ -377,7 +387,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert all(torch.isfinite(v).all() for v in out.values() if torch.is_tensor(v))
-    check = None if args.random_init else output_check(out, S, H, v0, v1, dev)
+    check = None if (args.random_init or emu) else output_check(out, S, H, v0, v1, dev)
     if world > 1 and check is not None:   # worst rank decides
         t = torch.tensor([check["max_l2"]], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -387,16 +397,20 @@ def main():
     if rank == 0:
         P = 5 + (H // 14) ** 2
         C = 1024
-        Nq, Nk = (S // world) * P, S * P
+        Nq, Nk = (S // (emu or world)) * P, S * P
         ms = sum(r[0] for r in recs) / max(len(recs), 1)
         flops = 4.0 * Nq * Nk * C
         achieved = flops / (ms * 1e-3) / 1e12
-        kernel_label = _C.attn_kernel_label(1, 16, Nq, Nk, precision.operand_name(), static_bound=precision.static_softmax(),
-                                            with_part_ws=True)
-        traffic = PMC_TRAFFIC.get(f"{S}x{H}x{world}:{kernel_label}", {})
+        if (world > 1 or emu) and precision.static_softmax():
+            kernel_label = (f"flash_attn_d64_v3_kernel<QB=2,KVM=2,{precision.operand_name()},static-bound> own keys + "
+                            f"{(emu or world) - 1} key segments + attn_combine_kernel")
+        else:
+            kernel_label = _C.attn_kernel_label(1, 16, Nq, Nk, precision.operand_name(), static_bound=precision.static_softmax(),
+                                                with_part_ws=True)
+        traffic = PMC_TRAFFIC.get(f"{S}x{H}x{emu or world}:{kernel_label}", {})
         line = {
             "metric": "views/sec (N-view 518^2 forward)",
-            "value": S * args.steps / dt,
+            "value": (v1 - v0 if emu else S) * args.steps / dt,
             "unit": "views/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -409,11 +423,19 @@ def main():
             "data": data,
             "graphs": bool(graphs),
             **({"graphs_note": graph_note} if graph_note else {}),
+            **({"emulated_rank": {"world": emu, "rank": shard.rank, "views_of_this_rank": v1 - v0,
+                                  "job_views_per_s_if_transport_were_free": S * args.steps / dt,
+                                  "note": "ONE GPU computing what a middle rank of a W-GPU run computes: per-rank shapes and byte "
+                                          "counts, gathers = local copies on the compute stream, outputs not the model's (other "
+                                          "ranks' keys are copies of this rank's); `value` = this rank's own views per second"}}
+               if emu else {}),
             **({"collectives": "forced: RCCL (backend nccl) in a world of one rank -- every all-gather of the sharded path "
                                "is issued, nothing leaves the device"} if force_coll else {}),
             "config": {"workload": f"{S} views @ {H}x{H}, IGGT forward (DINOv2 + 24x(frame,global) + camera/depth/"
-                                   "point heads), synthetic weights, views sharded " + f"{S // world}/GPU",
-                       "views": S, "image_size": H, "tokens_per_view": P, "parallelism": f"view-shard x{world}"},
+                                   "point heads), synthetic weights, views sharded " + f"{S // (emu or world)}/GPU"
+                                   + (f" (rank {shard.rank} of {emu} EMULATED on one GPU)" if emu else ""),
+                       "views": S, "image_size": H, "tokens_per_view": P,
+                       "parallelism": f"view-shard x{emu} (emulated rank)" if emu else f"view-shard x{world}"},
             "roofline": {"bound": "mfma", "kernel": kernel_label + " (global attention)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
@@ -446,7 +468,7 @@ def main():
                                      "frac": flops / (bf16_leg * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "ms_per_launch": bf16_leg}
         if check is not None:
             line["output_check"] = check
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not emu and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.cpu_sample_views, H)
             except Exception as ex:  # noqa: BLE001

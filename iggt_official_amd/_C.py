@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -40,9 +40,9 @@ _SIGNATURES = {
     "iggt_flash_attn_static_ws_bytes": [_c_int, _c_int, _c_int, _c_int],
     "iggt_flash_attn_static_ksplit": [_c_int, _c_int, _c_int, _c_int],
     "iggt_flash_attn_static_partial_bf16_d64": [_c_void_p] * 3 + [_c_int] * 4 + [_c_long] * 6
-                                              + [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p] * 3,
+                                              + [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p, _c_int] + [_c_void_p] * 3,
     "iggt_flash_attn_static_partial_f16_d64": [_c_void_p] * 3 + [_c_int] * 4 + [_c_long] * 6
-                                              + [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p] * 3,
+                                              + [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p, _c_int] + [_c_void_p] * 3,
     "iggt_flash_attn_static_combine_bf16_d64": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 4 + [_c_int] * 4 + [_c_long] * 8
                                               + [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "iggt_flash_attn_static_combine_f16_d64": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 4 + [_c_int] * 4 + [_c_long] * 8
@@ -270,18 +270,20 @@ def static_attn_ksplit(B, H, Nq, Nk):
 
 
 def flash_attn_d64_static_partial(q, k, v, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, qkmax, o_part, l_part, c_part,
-                                  slot0, ksplit, q_rows_per_wg=0, guard=None, guard_prev=None, seg_len=0, skip_seg=-1):
+                                  slot0, ksplit, q_rows_per_wg=0, guard=None, guard_prev=None, seg_len=0, skip_seg=-1,
+                                  seg_kmax=None):
     """Keys (k, v, Nk) -> partial slots [slot0, slot0 + ksplit) as `ksplit` equal key ranges, or (seg_len > 0) as the key
     segments of seg_len rows, leaving segment skip_seg out (include/iggt_hip.h)."""
-    _dev(q, k, v, qkmax, o_part, l_part, c_part, guard, guard_prev)
+    _dev(q, k, v, qkmax, o_part, l_part, c_part, guard, guard_prev, seg_kmax)
+    assert seg_kmax is None or (seg_kmax.dtype == torch.float32 and seg_kmax.is_contiguous() and seg_kmax.numel() >= 32 * ksplit)
     sfx = _h16(q, k, v, o_part)
     assert l_part.dtype == torch.float32 and c_part.dtype == torch.float32 and l_part.shape == c_part.shape
     assert o_part.is_contiguous() and l_part.is_contiguous() and c_part.is_contiguous()
     _guard_ok(guard), _guard_ok(guard_prev)
     fn = getattr(load(), f"iggt_flash_attn_static_partial_{sfx}_d64")
     rc = fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
-            qkmax.data_ptr(), o_part.data_ptr(), l_part.data_ptr(), c_part.data_ptr(), slot0, ksplit, seg_len, skip_seg,
-            q_rows_per_wg, _ptr(guard), _ptr(guard_prev), _stream())
+            _ptr(qkmax), o_part.data_ptr(), l_part.data_ptr(), c_part.data_ptr(), slot0, ksplit, seg_len, skip_seg,
+            _ptr(seg_kmax), q_rows_per_wg, _ptr(guard), _ptr(guard_prev), _stream())
     _check(rc, f"iggt_flash_attn_static_partial_{sfx}_d64")
 
 

@@ -60,7 +60,7 @@ int fill_params(AttnParams& p, const void* q, const void* k, const void* v, void
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs;
     p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.scale_log2 = 1.f; p.qtiles = 0; p.qkmax = nullptr; p.flags = nullptr; p.static_min_l = 0.f;
-    p.ksplit = 0; p.slot0 = 0; p.seg_len = 0; p.skip_seg = -1; p.o_part = nullptr; p.l_part = nullptr; p.c_part = nullptr;
+    p.ksplit = 0; p.slot0 = 0; p.seg_len = 0; p.skip_seg = -1; p.seg_kmax = nullptr; p.o_part = nullptr; p.l_part = nullptr; p.c_part = nullptr;
     p.guard = nullptr; p.guard_prev = nullptr; p.guard_retry = GUARD_RETRY_DEFAULT;
     return 0;
 }
@@ -106,13 +106,14 @@ static int flash_attn_h16(int fmt, const void* q, const void* k, const void* v, 
 static int flash_attn_static_partial_h16(int fmt, const void* q, const void* k, const void* v, int B, int H, int Nq, int Nk,
                                          long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
                                          const float* qkmax, void* o_part, float* l_part, float* c_part, int slot0,
-                                         int ksplit, int seg_len, int skip_seg, int q_rows_per_wg, const int* guard,
-                                         const int* guard_prev, void* stream) {
+                                         int ksplit, int seg_len, int skip_seg, const float* seg_kmax, int q_rows_per_wg,
+                                         const int* guard, const int* guard_prev, void* stream) {
     AttnParams p;
     const int rc = fill_params(p, q, k, v, o_part, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, 0, 64);
     if (rc) return rc;
-    if (qkmax == nullptr || o_part == nullptr || l_part == nullptr || c_part == nullptr || H > 16 || ksplit < 1 || slot0 < 0)
-        return -5;
+    if (o_part == nullptr || l_part == nullptr || c_part == nullptr || H > 16 || ksplit < 1 || slot0 < 0) return -5;
+    if (qkmax == nullptr && !(seg_len > 0 && seg_kmax != nullptr)) return -5;   // key bounds: per segment, or one for all
+    if (seg_kmax != nullptr && seg_len <= 0) return -5;
     p.guard = const_cast<int*>(guard); p.guard_prev = guard_prev; p.c_part = c_part;
     const int code = q_rows_per_wg ? q_rows_per_wg : 6256;
     if (!valid_code(code)) return -3;
@@ -122,7 +123,7 @@ static int flash_attn_static_partial_h16(int fmt, const void* q, const void* k, 
     } else if ((Nk + 64 * kvm - 1) / (64 * kvm) < ksplit || skip_seg != -1) {
         return -7;
     }
-    p.seg_len = seg_len > 0 ? seg_len : 0; p.skip_seg = skip_seg;
+    p.seg_len = seg_len > 0 ? seg_len : 0; p.skip_seg = skip_seg; p.seg_kmax = seg_kmax;
     p.qkmax = qkmax; p.ksplit = ksplit; p.slot0 = slot0; p.o_part = (bf16_t*)o_part; p.l_part = l_part;
     iggt_launch_flash_attn_v3(p, code % 1000, kvm, fmt, true, (hipStream_t)stream);
     IGGT_CHECK_LAUNCH();
@@ -175,7 +176,7 @@ static int flash_attn_static_h16(int fmt, const void* q, const void* k, const vo
             float* l_part = (float*)(ws + (long)ks * B * Nq * H * 64 * 2);
             float* c_part = l_part + (long)ks * B * Nq * H;
             int r = flash_attn_static_partial_h16(fmt, q, k, v, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, qkmax, ws,
-                                                  l_part, c_part, 0, ks, 0, -1, 6256, guard, guard_prev, stream);
+                                                  l_part, c_part, 0, ks, 0, -1, nullptr, 6256, guard, guard_prev, stream);
             if (r) return r;
             return flash_attn_static_combine_h16(fmt, ws, l_part, c_part, ks, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs,
                                                  v_bs, v_rs, o_bs, o_rs, flags, flags_len, 6256, guard, guard_prev, stream);
@@ -226,11 +227,11 @@ extern "C" int iggt_flash_attn_static_bf16_d64(const void* q, const void* k, con
 extern "C" int iggt_flash_attn_static_partial_bf16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq,
                                            int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
                                            const float* qkmax, void* o_part, float* l_part, float* c_part, int slot0,
-                                           int ksplit, int seg_len, int skip_seg, int q_rows_per_wg, const int* guard,
-                                           const int* guard_prev, void* stream) {
+                                           int ksplit, int seg_len, int skip_seg, const float* seg_kmax, int q_rows_per_wg,
+                                           const int* guard, const int* guard_prev, void* stream) {
     return flash_attn_static_partial_h16(FMT_BF16, q, k, v, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, qkmax, o_part,
-                                         l_part, c_part, slot0, ksplit, seg_len, skip_seg, q_rows_per_wg, guard, guard_prev,
-                                         stream);
+                                         l_part, c_part, slot0, ksplit, seg_len, skip_seg, seg_kmax, q_rows_per_wg, guard,
+                                         guard_prev, stream);
 }
 
 extern "C" int iggt_flash_attn_static_combine_bf16_d64(const void* o_part, const float* l_part, const float* c_part,
@@ -255,11 +256,11 @@ extern "C" int iggt_flash_attn_static_f16_d64(const void* q, const void* k, cons
 extern "C" int iggt_flash_attn_static_partial_f16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq,
                                            int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
                                            const float* qkmax, void* o_part, float* l_part, float* c_part, int slot0,
-                                           int ksplit, int seg_len, int skip_seg, int q_rows_per_wg, const int* guard,
-                                           const int* guard_prev, void* stream) {
+                                           int ksplit, int seg_len, int skip_seg, const float* seg_kmax, int q_rows_per_wg,
+                                           const int* guard, const int* guard_prev, void* stream) {
     return flash_attn_static_partial_h16(FMT_F16, q, k, v, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, qkmax, o_part,
-                                         l_part, c_part, slot0, ksplit, seg_len, skip_seg, q_rows_per_wg, guard, guard_prev,
-                                         stream);
+                                         l_part, c_part, slot0, ksplit, seg_len, skip_seg, seg_kmax, q_rows_per_wg, guard,
+                                         guard_prev, stream);
 }
 
 extern "C" int iggt_flash_attn_static_combine_f16_d64(const void* o_part, const float* l_part, const float* c_part,

@@ -27,6 +27,10 @@ struct AttnParams {
     // rank's own keys, already done from its local buffer while the gather was in flight; -1: none) is left out and the
     // segments after it move up one slot, so that every rank launches the same 7-of-8-ranges grid whatever its position
     int seg_len, skip_seg;
+    // segment mode only: per-segment key bounds, float [ksplit][32] -- the 32 norm maxima every rank's q/k-norm kernel leaves
+    // (entries 16..31 = keys), all-gathered next to the K/V rows; segment s is then shifted by its OWN rank's maximum (tighter
+    // than one maximum over all ranks, and no pass over the gathered keys).  nullptr: qkmax[16 + h] for every segment.
+    const float* seg_kmax;
     bf16_t* o_part;
     float* l_part;
     // per-row shift each partial was computed under, [slots][B][H][Nq] fp32 like l_part: segments launched with different key

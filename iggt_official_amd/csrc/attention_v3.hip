@@ -228,7 +228,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
             a2 += __shfl_xor(a2, 32, 64);
             n2 = fmaxf(n2, a2);
         }
-        const float shift = sqrtf(n2) * p.qkmax[16 + h] * 1.00002f + 1e-3f - (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
+        const float kmax = (PART && p.seg_kmax != nullptr) ? p.seg_kmax[ks * 32 + 16 + h] : p.qkmax[16 + h];
+        const float shift = sqrtf(n2) * kmax * 1.00002f + 1e-3f - (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
 #pragma unroll
         for (int r = 0; r < 16; ++r) cinit[r] = -shift;
     } else {

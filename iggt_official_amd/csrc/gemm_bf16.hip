@@ -353,13 +353,18 @@ static int gemm_h16(int fmt, const void* A, long lda, const void* W, long ldw, i
     // Exception: grids of < 128 big tiles (e.g. N = 1024 with a few thousand rows: the per-rank proj / fc2 GEMMs of an
     // 8-GPU run) leave most CUs idle -- the 128^2 kernel's 4x finer grid wins there (measured 108 vs 131 us).
     const long big_tiles = (long)((M + 255) / 256) * (N / 256);
-    // IGGT_GEMM_DUO (A/B switch): 1 = the 256 x 128 two-workgroups-per-CU kernel wherever it applies
+    // 256 x 128 two-workgroups-per-CU kernel (gemm_bf16_duo.hip): slower than the 256^2 tile on full grids (32 views: qkv 653
+    // vs 721, fc2 753 vs 901 TF/s -- 1.5x the LDS-DMA bytes per FLOP), faster where the 256^2 grid is one or two ragged rounds
+    // (M = 5 496, the per-rank shapes of an 8-GPU run: qkv 437 vs 417, fc1 516 vs 490, fc2 519 vs 500 TF/s; whole per-rank
+    // forward 67.4 -> 64.5 ms).  IGGT_GEMM_DUO: 0 never, 1 wherever it applies (A/B runs), default 2 = small grids only.
     static int duo = -1;
     if (duo < 0) {
         const char* e = getenv("IGGT_GEMM_DUO");
-        duo = e ? atoi(e) : 0;
+        duo = e ? atoi(e) : 2;
     }
-    if (duo == 1 && M >= 512 && (N % 128) == 0 && force_small_tile() == 0) {
+    const long duo_tiles = (long)((M + 255) / 256) * (N / 128);
+    const bool duo_auto = duo == 2 && M >= 1024 && duo_tiles <= 1024 && (big_tiles >= 128 || K >= 2048);
+    if ((duo == 1 || duo_auto) && M >= 512 && (N % 128) == 0 && force_small_tile() == 0) {
         const int rc = iggt_launch_gemm_duo(p, fmt, (hipStream_t)stream);
         if (rc == 0) {
             IGGT_CHECK_LAUNCH();

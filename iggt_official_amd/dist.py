@@ -82,34 +82,56 @@ class ViewShard:
             self._bufs[name] = cur
         return cur[:n].view(*shape)
 
-    def all_gather_kv(self, kv_local: torch.Tensor) -> torch.Tensor:
-        """kv_local [T_l, 2C] (contiguous) -> [world*T_l, 2C], rank-major = view-major token order."""
+    def all_gather_kv(self, kv_local: torch.Tensor, stats: Optional[torch.Tensor] = None):
+        """kv_local [T_l, 2C] (contiguous) -> [world*T_l, 2C], rank-major = view-major token order.  With `stats` (this
+        rank's 32 q/k norm maxima, fp32 [32]) returns (kv_all, stats_all [world, 32]): the key bounds travel with the keys."""
         assert kv_local.is_contiguous()
         out = self._buf("kv_all", (self.world * kv_local.shape[0], kv_local.shape[1]), kv_local)
-        self._step(lambda: self._gather(out, kv_local))
-        return out
+        if stats is None:
+            self._step(lambda: self._gather(out, kv_local))
+            return out
+        src, sout = self._stats_bufs(stats)
 
-    def all_gather_kv_begin(self, kv_local: torch.Tensor):
-        """Start the K/V all-gather without making the compute stream wait for it: returns (kv_all, finish) where
-        `finish()` must be called before kv_all is read.  Between the two calls the caller runs the part of the global
-        attention that only needs this rank's own keys (layers/blocks.py), hiding that much of the transport.  Under graph
-        capture both halves are eager steps between graph segments."""
+        def both():
+            self._gather(out, kv_local)
+            self._gather(sout, src)
+
+        self._step(both)
+        return out, sout
+
+    def _stats_bufs(self, stats):
+        assert stats.dtype == torch.float32 and stats.numel() == 32
+        src = self._buf("kv_stats_in", (32,), stats)
+        src.copy_(stats.reshape(32))                 # own copy: the caller's buffer is rewritten by the next block
+        return src, self._buf("kv_stats_all", (self.world, 32), stats)
+
+    def all_gather_kv_begin(self, kv_local: torch.Tensor, stats: Optional[torch.Tensor] = None):
+        """Start the K/V all-gather without making the compute stream wait for it: returns (kv_all, finish) -- or, with
+        `stats` (fp32 [32], see all_gather_kv), (kv_all, stats_all, finish) -- where `finish()` must be called before the
+        gathered buffers are read.  Between the two calls the caller runs the part of the global attention that only needs
+        this rank's own keys (layers/blocks.py), hiding that much of the transport.  Under graph capture both halves are
+        eager steps between graph segments."""
         assert kv_local.is_contiguous()
         out = self._buf("kv_all", (self.world * kv_local.shape[0], kv_local.shape[1]), kv_local)
+        src, sout = self._stats_bufs(stats) if stats is not None else (None, None)
         state = {}
 
-        def start():
+        def gather_async(dst, x):
             if self._flat():
-                state["work"] = dist.all_gather_into_tensor(out, kv_local, group=self.group, async_op=True)
-            else:
-                state["work"] = dist.all_gather(list(out.view(self.world, *kv_local.shape).unbind(0)), kv_local,
-                                                group=self.group, async_op=True)
+                return dist.all_gather_into_tensor(dst, x, group=self.group, async_op=True)
+            return dist.all_gather(list(dst.view(self.world, *x.shape).unbind(0)), x, group=self.group, async_op=True)
+
+        def start():
+            state["work"] = [gather_async(out, kv_local)] + ([gather_async(sout, src)] if src is not None else [])
 
         def finish():
-            state.pop("work").wait()      # RCCL: the current stream waits for the collective; gloo: the host does
+            for w in state.pop("work"):
+                w.wait()                      # RCCL: the current stream waits for the collective; gloo: the host does
 
         self._step(start)
-        return out, (lambda: self._step(finish))
+        if stats is None:
+            return out, (lambda: self._step(finish))
+        return out, sout, (lambda: self._step(finish))
 
     def _step(self, fn):
         """Run a collective now; under graph capture it is recorded as an eager step between two graph segments."""
@@ -162,3 +184,34 @@ class ViewShard:
         out = self._buf("rows_out", (self.world * x_local.shape[0],) + tuple(x_local.shape[1:]), x_local)
         self._step(lambda: self._gather(out, src))
         return out
+
+
+class EmulatedShard:
+    """DEVELOPER TOOL (bench.py --emulate-world, probes/emulate_rank.py): stands in for ViewShard on ONE GPU to measure what a
+    single rank of a `world`-GPU run computes.  The gathers are local copies -- this rank's rows repeated `world` times land in
+    the gathered buffers, so every kernel runs at the per-rank shapes with the right byte counts, but nothing is transported
+    and the other ranks' keys are copies of this rank's: the OUTPUTS ARE NOT THE MODEL'S (parity of the sharded path is what
+    tests/test_shard_gpu.py and tests/test_headline_gpu.py check).  The copies run on the compute stream and are counted
+    (RCCL's transport would overlap with the own-key attention)."""
+    active, force, kv_groups = True, False, 1
+
+    def __init__(self, world: int, rank: Optional[int] = None):
+        self.world = int(world)
+        self.rank = self.world // 2 if rank is None else int(rank)     # a middle rank: rank 0 is not the typical one
+        self.ctl = None
+
+    def local_views(self, S: int) -> Tuple[int, int]:
+        return view_partition(S, self.world, self.rank)
+
+    def all_gather_kv(self, kv, stats=None):
+        out = kv.repeat(self.world, 1)
+        return out if stats is None else (out, stats.reshape(1, 32).repeat(self.world, 1))
+
+    def all_gather_kv_begin(self, kv, stats=None):
+        out = kv.repeat(self.world, 1)
+        if stats is None:
+            return out, (lambda: None)
+        return out, stats.reshape(1, 32).repeat(self.world, 1), (lambda: None)
+
+    def all_gather_rows(self, x):
+        return x.repeat(self.world, *([1] * (x.dim() - 1)))

@@ -252,9 +252,9 @@ class Block(nn.Module):
                 kv_local = ws.get("kv_local", (T, 2 * C), dt, dev)
                 _C.qknorm_rope(qkv, qkv, kv_local, kv_local[:, C:], *qk_args, **sk)
                 assert batch == 1
-                if static and q_rows_per_wg == 0 and hasattr(kv_gather, "all_gather_kv_begin") and kv_gather.active \
-                        and precision.gather_overlap():
-                    overlapped = self._attend_overlapped(qkv, kv_local, kv_gather, qkmax, ao, ws, T, H, C, guard, guard_prev)
+                if static and q_rows_per_wg == 0 and hasattr(kv_gather, "all_gather_kv_begin") and kv_gather.active:
+                    overlapped = self._attend_overlapped(qkv, kv_local, kv_gather, qkmax, ao, ws, T, H, C, guard, guard_prev,
+                                                         overlap=precision.gather_overlap())
                 else:
                     kv_all = gather(kv_local)
                     k_src, v_src, kv_rs, Nk, k_bs = kv_all, kv_all[:, C:], 2 * C, kv_all.shape[0], 0
@@ -313,38 +313,40 @@ class Block(nn.Module):
             _C.gemm_h16(hid, pk["w_fc2"], x2d, bias=b_, gamma=pk["g2"], accumulate=True)
         return x2d
 
-    def _attend_overlapped(self, qkv, kv_local, shard, qkmax, ao, ws, T, H, C, guard=None, guard_prev=None):
-        """Multi-GPU global attention with the K/V all-gather hidden behind the attention over this rank's own keys.
-        Under the static softmax bound partial results over disjoint key sets combine by a re-weighting that depends only on
-        the shifts they were computed under (csrc/attention_v3.hip attn_combine_kernel), so the keys are processed as
-        segments:
-          1. own keys (from kv_local, while the gather is in flight; key bound = this rank's measured maximum), cut into as
-             many ranges as fill the chip (352 query tiles for 512 workgroup slots at 4 views / rank: 4 ranges);
-          2. the key bound of the gathered rows (one HBM pass, csrc/elementwise.hip krownorm_kernel);
-          3. ONE launch over the gathered buffer in segment mode: one key range per rank, this rank's own segment left out
-             -- the same (world - 1) x query-tiles grid on every rank (two launches "ranks before / ranks after" cost a
-             middle rank 6 rounds of workgroups where rank 0 needed 5);
-          4. the combine kernel folds the slots and runs the flagged-tile fallback over all keys."""
+    def _attend_overlapped(self, qkv, kv_local, shard, qkmax, ao, ws, T, H, C, guard=None, guard_prev=None, overlap=True):
+        """Multi-GPU global attention on the static-bound kernel, the K/V all-gather hidden behind the attention over this
+        rank's own keys.  Partial results over disjoint key sets combine by a re-weighting that depends only on the shifts
+        they were computed under (csrc/attention_v3.hip attn_combine_kernel), so the keys are processed as segments:
+          1. the gather starts: K/V rows and, beside them, the 32 norm maxima the q/k-norm kernel just left -- every rank's key
+             bound travels with its keys (64 bytes);
+          2. own keys (from kv_local, while the gather is in flight; bound = this rank's maximum) -> slot world - 1;
+          3. ONE launch over the gathered buffer in segment mode: one key range per rank, each under its OWN rank's bound, this
+             rank's segment left out -- the same (world - 1) x query-tiles grid on every rank (two launches "ranks before /
+             ranks after" cost a middle rank 6 rounds of workgroups where rank 0 needed 5) -> slots 0 .. world - 2;
+          4. the combine kernel folds the slots and runs the flagged-tile fallback over all keys.
+        overlap = False (IGGT_GATHER_OVERLAP=0): the gather completes first; same kernels."""
         W, r = shard.world, shard.rank
         dt, dev = qkv.dtype, qkv.device
-        ks_own = _C.static_attn_ksplit(1, H, T, T)
-        nslots = W - 1 + ks_own
-        o_part = ws.get("attn_opart", (nslots, 1, T, C), dt, dev)
-        l_part = ws.get("attn_lpart", (nslots, 1, H, T), torch.float32, dev)
-        c_part = ws.get("attn_cpart", (nslots, 1, H, T), torch.float32, dev)
+        o_part = ws.get("attn_opart", (W, 1, T, C), dt, dev)
+        l_part = ws.get("attn_lpart", (W, 1, H, T), torch.float32, dev)
+        c_part = ws.get("attn_cpart", (W, 1, H, T), torch.float32, dev)
         flags = ws.get("attn_flags", (H * ((T + 127) // 128),), torch.int32, dev)
-        qkmax_all = ws.get("qkmax_all", (_C.QKMAX_NUMEL,), torch.float32, dev)
         g = dict(guard=guard, guard_prev=guard_prev)
         with profiling.region("global_attn", (1, T, W * T)):
-            kv_all, finish = shard.all_gather_kv_begin(kv_local)
+            if overlap:
+                kv_all, stats_all, finish = shard.all_gather_kv_begin(kv_local, qkmax[:32])
+            else:
+                kv_all, stats_all = shard.all_gather_kv(kv_local, qkmax[:32])
+                finish = None
             _C.flash_attn_d64_static_partial(qkv, kv_local, kv_local[:, C:], 1, H, T, T, 0, 3 * C, 0, 2 * C, 0, 2 * C, qkmax,
-                                             o_part, l_part, c_part, W - 1, ks_own, **g)
-            finish()
+                                             o_part, l_part, c_part, W - 1, 1, **g)
+            if finish is not None:
+                finish()
             if W > 1:
-                _C.k_rownorm_max(kv_all[:, :C], qkmax_all)
                 _C.flash_attn_d64_static_partial(qkv, kv_all, kv_all[:, C:], 1, H, T, W * T, 0, 3 * C, 0, 2 * C, 0, 2 * C,
-                                                 qkmax_all, o_part, l_part, c_part, 0, W, seg_len=T, skip_seg=r, **g)
-            _C.flash_attn_d64_static_combine(o_part, l_part, c_part, nslots, qkv, kv_all, kv_all[:, C:], ao, 1, H, T, W * T, 0,
+                                                 None, o_part, l_part, c_part, 0, W, seg_len=T, skip_seg=r, seg_kmax=stats_all,
+                                                 **g)
+            _C.flash_attn_d64_static_combine(o_part, l_part, c_part, W, qkv, kv_all, kv_all[:, C:], ao, 1, H, T, W * T, 0,
                                              3 * C, 0, 2 * C, 0, 2 * C, 0, C, flags, **g)
         return True
 

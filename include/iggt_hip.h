@@ -97,19 +97,22 @@ int iggt_flash_attn_static_ksplit(int B, int H, int Nq, int Nk);
  *              (s + 1) * seg_len) -- one rank's rows of the gathered buffer each; segment skip_seg (-1: none) is left out
  *              and the later ones move up one slot: every rank of a view-sharded run launches the same (world - 1)-range
  *              grid over the gathered buffer whatever its position.  seg_len = 0: equal shares of the key tiles.
+ *              seg_kmax (segment mode; NULL: qkmax for every segment): float [ksplit][32], the qkmax heads of the ranks as
+ *              iggt_qknorm_rope_* left them, all-gathered beside the K/V rows -- segment s is bounded by seg_kmax[s][16 + h],
+ *              its own rank's key maximum (qkmax may then be NULL).
  *   _combine_: o = sum_s w_s O_s / sum_s w_s over nslots slots, then the flag / online-max fallback pass over the full key
  *              set (k, v, Nk).  q_rows_per_wg: 0 (= 6256) or the code both calls were given.  guard / guard_prev as above
  *              (the partial launches only read them). */
 int iggt_flash_attn_static_partial_bf16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq, int Nk,
                                             long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
                                             const float* qkmax, void* o_part, float* l_part, float* c_part, int slot0,
-                                            int ksplit, int seg_len, int skip_seg, int q_rows_per_wg, const int* guard,
-                                            const int* guard_prev, void* stream);
+                                            int ksplit, int seg_len, int skip_seg, const float* seg_kmax, int q_rows_per_wg,
+                                            const int* guard, const int* guard_prev, void* stream);
 int iggt_flash_attn_static_partial_f16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq, int Nk,
                                            long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,
                                            const float* qkmax, void* o_part, float* l_part, float* c_part, int slot0,
-                                           int ksplit, int seg_len, int skip_seg, int q_rows_per_wg, const int* guard,
-                                           const int* guard_prev, void* stream);
+                                           int ksplit, int seg_len, int skip_seg, const float* seg_kmax, int q_rows_per_wg,
+                                           const int* guard, const int* guard_prev, void* stream);
 int iggt_flash_attn_static_combine_bf16_d64(const void* o_part, const float* l_part, const float* c_part, int nslots,
                                             const void* q, const void* k, const void* v, void* o, int B, int H, int Nq,
                                             int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs,

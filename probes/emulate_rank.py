@@ -11,34 +11,9 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 SIZE = int(sys.argv[3]) if len(sys.argv) > 3 else 518
 
 
-class FakeShard:
-    # a MIDDLE rank by default: rank 0 owns view 0 and (before round 3) had the cheapest key-segment layout
-    rank, world, active = int(os.environ.get("IGGT_EMU_RANK", str(N // 2))), N, True
-    kv_groups = int(os.environ.get("IGGT_KV_GROUPS", "1"))
-    force = False
-    _streams, _events = [], []
+from iggt_official_amd.dist import EmulatedShard  # noqa: E402
 
-    def gather_kv_groups(self, kv_local):
-        return [(None, kv_local[g].repeat(N, 1)) for g in range(kv_local.shape[0])]
-
-    def side_stream(self, g):
-        while len(self._streams) <= g:
-            self._streams.append(torch.cuda.Stream())
-        return self._streams[g]
-
-    def event(self, i):
-        while len(self._events) <= i:
-            self._events.append(torch.cuda.Event())
-        return self._events[i]
-
-    def all_gather_kv(self, kv):
-        return kv.repeat(N, 1)
-
-    def all_gather_kv_begin(self, kv):     # overlap path (own keys first): same bytes land, no transport to hide here
-        return kv.repeat(N, 1), (lambda: None)   # (the copy runs on the compute stream: it is counted, RCCL's would overlap)
-
-    def all_gather_rows(self, x):
-        return x.repeat(N, *([1] * (x.dim() - 1)))
+FakeShard = lambda: EmulatedShard(N, int(os.environ["IGGT_EMU_RANK"]) if "IGGT_EMU_RANK" in os.environ else None)  # noqa: E731
 
 
 torch.manual_seed(0)

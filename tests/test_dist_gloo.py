@@ -37,6 +37,15 @@ def _worker(rank, world, port, ret):
         assert (v0, v1) == view_partition(S, world, rank) and (v1 - v0) * world == S
         kv_all = shard.all_gather_kv(kv[v0 * P:v1 * P].contiguous())
         assert torch.equal(kv_all, kv)          # rank-major == view-major order
+        # the key bounds travel with the keys: every rank's 32 norm maxima land in row `rank` of a [world, 32] buffer
+        stats = torch.arange(32, dtype=torch.float32) + 100.0 * rank
+        kv2, st_all = shard.all_gather_kv(kv[v0 * P:v1 * P].contiguous(), stats)
+        want = torch.stack([torch.arange(32, dtype=torch.float32) + 100.0 * r for r in range(world)])
+        assert torch.equal(kv2, kv) and torch.equal(st_all, want)
+        kv3, st3, fin = shard.all_gather_kv_begin(kv[v0 * P:v1 * P].contiguous(), stats + 1.0)
+        stats.fill_(-1.0)                        # the caller may rewrite its buffer at once: the shard keeps its own copy
+        fin()
+        assert torch.equal(kv3, kv) and torch.equal(st3, want + 1.0)
 
         def attn(qr, kvm):
             qh = qr.view(-1, H, D).transpose(0, 1)
