@@ -363,7 +363,8 @@ static int gemm_h16(int fmt, const void* A, long lda, const void* W, long ldw, i
         duo = e ? atoi(e) : 2;
     }
     const long duo_tiles = (long)((M + 255) / 256) * (N / 128);
-    const bool duo_auto = duo == 2 && M >= 1024 && duo_tiles <= 1024 && (big_tiles >= 128 || K >= 2048);
+    // (at 8 / 16 views -- M = 10 992 / 21 984 -- the 256^2 tile wins on every shape again: fc2 740 vs 593, fc1 636 vs 576 TF/s)
+    const bool duo_auto = duo == 2 && M >= 1024 && M < 8192 && duo_tiles <= 1024 && (big_tiles >= 128 || K >= 2048);
     if ((duo == 1 || duo_auto) && M >= 512 && (N % 128) == 0 && force_small_tile() == 0) {
         const int rc = iggt_launch_gemm_duo(p, fmt, (hipStream_t)stream);
         if (rc == 0) {

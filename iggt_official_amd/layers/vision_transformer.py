@@ -74,9 +74,13 @@ class DinoVisionTransformer(nn.Module):
         reference vision_transformer.py:183-215 (`size=` branch, interpolate_offset = 0.0)."""
         key = (H, W, self.pos_embed._version, self.pos_embed.data_ptr(), self.cls_token._version,
                None if self.register_tokens is None else self.register_tokens._version)
-        if self._cache.get("pos_key") != key:
-            if "pos" in self._cache:
-                graphs.buffers_changed()    # the tables of the previous (H, W) / parameters are freed below
+        tables = self._cache.setdefault("pos_tables", {})
+        if key not in tables:
+            # one entry per (H, W, parameter version): alternating input shapes must not free each other's tables -- captured
+            # graphs hold their addresses (graphs.py); the oldest entries go once 16 shapes have been seen
+            while len(tables) >= 16:
+                tables.pop(next(iter(tables)))
+                graphs.buffers_changed()
             pe = self.pos_embed.detach().float()
             N = pe.shape[1] - 1
             gh, gw = H // self.patch_size, W // self.patch_size
@@ -93,9 +97,8 @@ class DinoVisionTransformer(nn.Module):
             special = [self.cls_token.detach().float()[0] + pe[0, :1]]
             if self.register_tokens is not None:
                 special.append(self.register_tokens.detach().float()[0])
-            self._cache["pos_key"] = key
-            self._cache["pos"] = (torch.cat(special, 0).contiguous(), patch_pe.contiguous())
-        return self._cache["pos"]
+            tables[key] = (torch.cat(special, 0).contiguous(), patch_pe.contiguous())
+        return tables[key]
 
     def _packed_patch_weight(self):
         w = self.patch_embed.proj.weight

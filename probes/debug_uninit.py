@@ -20,11 +20,10 @@ a = weights.make_images(*shape, seed=1, device="cuda")
 def run(x):
     cap = {}
     h1 = model.aggregator.register_forward_hook(lambda m, i, o: cap.__setitem__("tokens", {i: t.clone() for i, t in enumerate(o[0]) if t is not None}))
-    h2 = model.aggregator.patch_embed.register_forward_hook(lambda m, i, o: cap.__setitem__("dino", o["x_norm_patchtokens"].clone()))
     out = model(x)
-    h1.remove(), h2.remove()
+    h1.remove()
     torch.cuda.synchronize()
-    d = {"dino": cap["dino"]}
+    d = {}
     for i, t in cap["tokens"].items():
         d[f"tokens{i}"] = t
     for k, v in out.items():

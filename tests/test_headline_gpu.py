@@ -133,8 +133,8 @@ def test_sharded_global_attention_at_production_shapes(C, dtype, cfg):
     Nk = W * T
     g = torch.Generator(device="cuda").manual_seed(77)
     kv_all = torch.randn(Nk, 2 * Cdim, generator=g, device="cuda", dtype=torch.float32).to(dtype)
-    # per-rank differences in the key norms (every rank normalises its own views): rank 6's keys are 15 % larger
-    kv_all[6 * T:7 * T, :Cdim] *= 1.15
+    # per-rank differences in the key norms (every rank normalises its own views): rank 6's keys are 30 % larger
+    kv_all[6 * T:7 * T, :Cdim] *= 1.3
     qkv = torch.randn(T, 3 * Cdim, generator=g, device="cuda", dtype=torch.float32).to(dtype)
     qkv[:, :Cdim] *= 0.125 * 1.4426950408889634            # |q^| ~ 1.44, |k| ~ 8: the model's LayerNorm-ed magnitudes
     kv_local = kv_all[r * T:(r + 1) * T].clone()
@@ -145,7 +145,7 @@ def test_sharded_global_attention_at_production_shapes(C, dtype, cfg):
     for s in range(W):                                        # what every rank's qknorm_rope leaves for its own keys
         C.k_rownorm_max(kv_all[s * T:(s + 1) * T, :Cdim], qkmax)
         stats_all[s] = qkmax[:32]
-    assert float(stats_all[6, 16:].min() / stats_all[5, 16:].max()) > 1.05      # rank 6 really has the larger keys
+    assert float((stats_all[6, 16:] / stats_all[5, 16:]).min()) > 1.05          # rank 6 really has the larger keys
     C.k_rownorm_max(kv_local[:, :Cdim], qkmax)
     ao = torch.full((T, Cdim), float("nan"), dtype=dtype, device="cuda")
     guard = C.new_attn_guard("cuda")
