@@ -439,13 +439,15 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnParams p, i
     }
     for (int c = threadIdx.x * 4; c < C; c += 256 * 4) {
         const int h = c >> 6;
-        float L = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float L = 0.f, wsum = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
         // segments may have been computed under different shifts (different key bounds): weights l_s 2^(shift_s - shift_max)
         float cmax = -INFINITY;
         for (int s = 0; s < nslots; ++s) cmax = fmaxf(cmax, p.c_part[(((long)s * p.B + b) * p.H + h) * (long)p.Nq + qr]);
         for (int s = 0; s < nslots; ++s) {
             const long li = (((long)s * p.B + b) * p.H + h) * (long)p.Nq + qr;
-            const float l = p.l_part[li] * __builtin_amdgcn_exp2f(p.c_part[li] - cmax);
+            const float wgt = __builtin_amdgcn_exp2f(p.c_part[li] - cmax);
+            const float l = p.l_part[li] * wgt;
+            wsum += wgt;
             const u32x2 w = *reinterpret_cast<const u32x2*>(p.o_part + (((long)s * p.B + b) * p.Nq + qr) * (long)C + c);
             L += l;
             acc[0] += l * h2_lo<FMT>(w[0]); acc[1] += l * h2_hi<FMT>(w[0]);
@@ -456,7 +458,11 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnParams p, i
         o[0] = pack_h2<FMT>(acc[0] * inv, acc[1] * inv);
         o[1] = pack_h2<FMT>(acc[2] * inv, acc[3] * inv);
         *reinterpret_cast<u32x2*>(p.o + (long)b * p.o_bs + (long)qr * p.o_rs + c) = o;
-        if ((c & 63) == 0 && !(L >= p.static_min_l)) p.flags[((long)b * p.H + h) * p.qtiles + qr / tile_rows] = 1;
+        // acceptance (attention_common.h): the mass a segment can have lost to fp16 flushing is bounded under ITS OWN shift --
+        // n_s 2^-24 there, n_s 2^-24 2^(shift_s - shift_max) in the common units of L -- so the threshold is the per-key one
+        // times sum_s n_s w_s (segments of equal length: Nk / nslots each), not times Nk
+        if ((c & 63) == 0 && !(L >= p.static_min_l * (wsum / (float)nslots)))
+            p.flags[((long)b * p.H + h) * p.qtiles + qr / tile_rows] = 1;
     }
 }
 
