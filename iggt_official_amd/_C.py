@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -115,6 +115,9 @@ _SIGNATURES = {
     "iggt_track_tokens_f32": [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_long, _c_int, _c_void_p, _c_long,
                               _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_float, _c_void_p],
     "iggt_track_update_f32": [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_int, _c_int, _c_float, _c_void_p],
+    "iggt_hdbscan_core_dist_f32": [_c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p],
+    "iggt_hdbscan_nearest_foreign_f32": [_c_void_p] * 6 + [_c_long, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "iggt_hdbscan_labels_from_mst": [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, ctypes.c_double, _c_int, _c_void_p],
     "iggt_write_special_tokens": [_c_void_p, _c_long, _c_long, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_void_p],
 }
@@ -880,3 +883,46 @@ def track_update(coords, delta, pred, stride):
                                       float(stride), _stream())
     _check(rc, "iggt_track_update_f32")
     return pred
+
+
+# ------------------------------------------------------------------------------------------------
+# HDBSCAN (csrc/hdbscan.hip, csrc/hdbscan_tree.hip)
+def hdbscan_core_dist(x, k):
+    """x fp32 [M, C] (device, C in {3, 8, 16}) -> core distances fp32 [M]: distance to the k-th nearest row, itself counted."""
+    _dev(x)
+    _f32_all(x)
+    M, C = x.shape
+    core = torch.empty(M, dtype=torch.float32, device=x.device)
+    _check(load().iggt_hdbscan_core_dist_f32(x.data_ptr(), M, C, int(k), core.data_ptr(), _stream()), "iggt_hdbscan_core_dist_f32")
+    return core
+
+
+def hdbscan_nearest_foreign(x, core2, comp, idx, tile_lo, tile_hi):
+    """One Boruvka round (include/iggt_hip.h): arrays ordered by component -> (best_w2 fp32 [M], best_p int32 [M])."""
+    _dev(x, core2, comp, idx, tile_lo, tile_hi)
+    _f32_all(x, core2)
+    M, C = x.shape
+    for t in (comp, idx, tile_lo, tile_hi):
+        assert t.dtype == torch.int32 and t.is_contiguous()
+    assert tile_lo.numel() == (M + 255) // 256 == tile_hi.numel()
+    w2 = torch.empty(M, dtype=torch.float32, device=x.device)
+    bp = torch.empty(M, dtype=torch.int32, device=x.device)
+    rc = load().iggt_hdbscan_nearest_foreign_f32(x.data_ptr(), core2.data_ptr(), comp.data_ptr(), idx.data_ptr(), tile_lo.data_ptr(),
+                                                 tile_hi.data_ptr(), M, C, w2.data_ptr(), bp.data_ptr(), _stream())
+    _check(rc, "iggt_hdbscan_nearest_foreign_f32")
+    return w2, bp
+
+
+def hdbscan_labels_from_mst(eu, ev, ew, n_points, min_cluster_size, eps=0.0, allow_single_cluster=False):
+    """HOST walk over the spanning tree (numpy int32 / int32 / float32 arrays of n_points - 1 edges) -> labels int32 [n_points]."""
+    import numpy as np
+
+    eu = np.ascontiguousarray(eu, dtype=np.int32)
+    ev = np.ascontiguousarray(ev, dtype=np.int32)
+    ew = np.ascontiguousarray(ew, dtype=np.float32)
+    assert eu.shape == ev.shape == ew.shape == (max(int(n_points) - 1, 0),)
+    labels = np.empty(int(n_points), dtype=np.int32)
+    rc = load().iggt_hdbscan_labels_from_mst(eu.ctypes.data, ev.ctypes.data, ew.ctypes.data, int(n_points), int(min_cluster_size),
+                                             float(eps or 0.0), int(bool(allow_single_cluster)), labels.ctypes.data)
+    _check(rc, "iggt_hdbscan_labels_from_mst")
+    return labels

@@ -1,0 +1,111 @@
+"""HDBSCAN on the GPU -- the clustering step of `cluster_features_to_masks_mv` (reference iggt/utils/misc.py:123-129:
+`HDBSCAN(cluster_selection_epsilon=eps, min_samples=..., min_cluster_size=..., allow_single_cluster=False).fit(pixels).labels_`
+with cuml's / hdbscan's / scikit-learn's estimator, misc.py:19-22; caller demo.py:385-394 on all N * H * W pixels' part features).
+
+The algorithm (Campello, Moulavi, Sander 2013; cluster_selection_epsilon: Malzer & Baum 2020), exact, in three stages:
+  1. core distances: distance to the min_samples-th nearest point, itself counted       -- csrc/hdbscan.hip, brute force, fp32
+  2. minimum spanning tree of the mutual-reachability graph max(core_i, core_j, d_ij), by Boruvka rounds: every round one kernel
+     finds, for every point, the cheapest edge into another component (edges totally ordered by (weight, min index, max index));
+     the per-component minimum, the hooking of components and the pointer jumping are torch index operations on M-element arrays
+  3. dendrogram -> condensed tree -> excess-of-mass selection -> epsilon -> labels: a walk over the M - 1 edges on the host
+     (csrc/hdbscan_tree.hip, pure host code, checked against scikit-learn on the CPU by tests/test_hdbscan.py)
+Labels agree with scikit-learn's up to the numbering of the clusters (the numbering follows the orientation of the spanning-tree
+edges, which no two implementations share) and up to fp32-vs-fp64 ties on borderline points.  No CPU fallback: the points must be on
+the GPU."""
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _C
+
+_SUPPORTED_C = (3, 8, 16)
+
+
+def _pad_channels(x: torch.Tensor) -> torch.Tensor:
+    C = x.shape[1]
+    for c in _SUPPORTED_C:
+        if C <= c:
+            if C == c:
+                return x.contiguous()
+            out = torch.zeros(x.shape[0], c, dtype=torch.float32, device=x.device)
+            out[:, :C] = x                       # zero columns do not change any distance
+            return out
+    raise _C.HipExtensionError(f"hdbscan: at most {_SUPPORTED_C[-1]} feature channels are built (got {C})")
+
+
+def mutual_reachability_mst(x: torch.Tensor, min_samples: int, _kernels=None):
+    """x fp32 [M, C] on the GPU -> (eu, ev int64 [M - 1], ew fp32 [M - 1]) spanning-tree edges (original indices, weights =
+    mutual-reachability distances) and the core distances fp32 [M].
+    `_kernels`: (core_dist, nearest_foreign) stand-ins with the signatures of the two _C entry points -- ONLY for the CPU test of
+    the round logic below (tests/test_hdbscan.py injects torch re-statements); the product never passes it."""
+    core_dist, nearest_foreign = _kernels or (_C.hdbscan_core_dist, _C.hdbscan_nearest_foreign)
+    if not x.is_cuda and _kernels is None:
+        raise _C.HipExtensionError("hdbscan runs on the GPU (no CPU fallback)")
+    x = _pad_channels(x.detach().float())
+    M = x.shape[0]
+    if min_samples > M:
+        raise ValueError(f"min_samples ({min_samples}) must be at most the number of samples ({M})")
+    dev = x.device
+    core = core_dist(x, int(min_samples))
+    core2 = core * core
+    comp = torch.arange(M, dtype=torch.int64, device=dev)          # component id of every point (original order)
+    big = torch.iinfo(torch.int64).max
+    eu, ev, ew = [], [], []
+    ncomp = M
+    while ncomp > 1:
+        comps, order = torch.sort(comp, stable=True)               # positions sorted by component
+        xs, c2s = x[order].contiguous(), core2[order].contiguous()
+        ntile = (M + 255) // 256
+        padded = torch.cat([comps, comps[-1:].expand(ntile * 256 - M)]).view(ntile, 256)
+        w2, bp = nearest_foreign(xs, c2s, comps.int().contiguous(), order.int().contiguous(),
+                                            padded.amin(1).int().contiguous(), padded.amax(1).int().contiguous())
+        oi, oj = order, order[bp.long()]
+        lo, hi = torch.minimum(oi, oj), torch.maximum(oi, oj)
+        # cheapest outgoing edge of every component under the total order (weight, lo, hi)
+        wmin = torch.full((M,), float("inf"), device=dev).scatter_reduce(0, comps, w2, "amin")
+        key = torch.where(w2 == wmin[comps], lo * M + hi, torch.full_like(lo, big))
+        kmin = torch.full((M,), big, dtype=torch.int64, device=dev).scatter_reduce(0, comps, key, "amin")
+        roots = torch.unique(comps)
+        ekey, ew2 = kmin[roots], wmin[roots]
+        elo, ehi = ekey // M, ekey % M
+        ukey, first = np.unique(ekey.cpu().numpy(), return_index=True)   # two components may pick the same edge: keep it once
+        first = torch.from_numpy(first).to(dev)
+        eu.append(elo[first])
+        ev.append(ehi[first])
+        ew.append(torch.sqrt(ew2[first]))
+        # hook every component onto the component at the other end of its edge; a mutual pair keeps the smaller id as root
+        ca, cb = comp[elo], comp[ehi]
+        other = torch.where(ca == roots, cb, ca)
+        parent = torch.arange(M, dtype=torch.int64, device=dev)
+        parent[roots] = other
+        mutual = (parent[parent[roots]] == roots) & (roots < other)
+        parent[roots[mutual]] = roots[mutual]
+        while True:                                                # pointer jumping
+            nxt = parent[parent]
+            if torch.equal(nxt, parent):
+                break
+            parent = nxt
+        comp = parent[comp]
+        n_new = int(torch.unique(comp).numel())
+        if n_new >= ncomp:
+            raise _C.HipExtensionError("hdbscan: a Boruvka round merged nothing (non-finite features?)")
+        ncomp = n_new
+    eu, ev, ew = torch.cat(eu), torch.cat(ev), torch.cat(ew)
+    if eu.numel() != M - 1:
+        raise _C.HipExtensionError(f"hdbscan: spanning tree has {eu.numel()} edges for {M} points")
+    return eu, ev, ew, core
+
+
+def hdbscan_labels(x: torch.Tensor, min_cluster_size: int, min_samples: Optional[int] = None,
+                   cluster_selection_epsilon: float = 0.0, allow_single_cluster: bool = False, _kernels=None) -> np.ndarray:
+    """x fp32 [M, C] on the GPU -> int32 labels [M] (numpy; -1 = noise), the estimator call of misc.py:123-129."""
+    M = x.shape[0]
+    if min_cluster_size is None or int(min_cluster_size) < 2:
+        raise ValueError("min_cluster_size must be an integer >= 2")
+    k = int(min_cluster_size if min_samples is None else min_samples)
+    if M == 1:
+        return np.full(1, -1, dtype=np.int32)
+    eu, ev, ew, _ = mutual_reachability_mst(x, k, _kernels)
+    return _C.hdbscan_labels_from_mst(eu.cpu().numpy(), ev.cpu().numpy(), ew.cpu().numpy(), M, int(min_cluster_size),
+                                      float(cluster_selection_epsilon or 0.0), allow_single_cluster)

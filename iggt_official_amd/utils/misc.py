@@ -11,9 +11,11 @@ Same names, argument meaning and return shapes as the reference functions; the a
   covariance is accumulated in two passes on the GPU and diagonalised in fp64; the sign of every axis is fixed (largest-
   magnitude component positive), so the colours are deterministic.  A flipped axis maps a channel c to 1 - c (the 2 % / 98 %
   stretch is symmetric); tests compare up to that flip.
-* `cluster_features_to_masks_mv` (misc.py:81-170): HDBSCAN itself stays a host library call (hdbscan / cuml when installed,
-  as the reference imports them, else scikit-learn's implementation); the nearest-labelled-pixel fill of the noise pixels and
-  the colouring run on the GPU.
+* `cluster_features_to_masks_mv` (misc.py:81-170): HDBSCAN on the GPU (utils/hdbscan.py: exact core distances and the
+  mutual-reachability spanning tree by Boruvka rounds as brute-force HIP kernels, csrc/hdbscan.hip; dendrogram / condensed tree /
+  excess-of-mass / epsilon on the host, csrc/hdbscan_tree.hip) -- the reference calls cuml's, hdbscan's or scikit-learn's
+  estimator (misc.py:19-22,123-129); labels agree with scikit-learn's up to the cluster numbering.  The nearest-labelled-pixel
+  fill of the noise pixels and the colouring run on the GPU as well.
 """
 from typing import Tuple, Union
 
@@ -105,18 +107,11 @@ def apply_pca_colormap(image: torch.Tensor) -> torch.Tensor:
     return col.view(n, h, w, 3)
 
 
-def _hdbscan(pixels: np.ndarray, eps, min_samples, min_cluster_size) -> np.ndarray:
-    kw = dict(cluster_selection_epsilon=eps, min_samples=min_samples, min_cluster_size=min_cluster_size,
-              allow_single_cluster=False)
-    try:
-        from cuml.cluster.hdbscan import HDBSCAN          # same preference order as the reference (misc.py:19-22)
-    except Exception:  # noqa: BLE001
-        try:
-            from hdbscan import HDBSCAN
-        except Exception:  # noqa: BLE001
-            from sklearn.cluster import HDBSCAN
-            kw["cluster_selection_epsilon"] = float(eps) if eps is not None else 0.0
-    return np.asarray(HDBSCAN(**kw).fit(pixels).labels_)
+def _hdbscan(pix: torch.Tensor, eps, min_samples, min_cluster_size) -> np.ndarray:
+    """The estimator call of the reference (misc.py:123-129) on the GPU: iggt_official_amd/utils/hdbscan.py."""
+    from .hdbscan import hdbscan_labels
+
+    return hdbscan_labels(pix, min_cluster_size, min_samples, float(eps) if eps is not None else 0.0, allow_single_cluster=False)
 
 
 def fill_noise_labels(pixels: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
@@ -145,16 +140,16 @@ def _jet_colors(n_colors: int) -> np.ndarray:
 def cluster_features_to_masks_mv(feature_map: Union[torch.Tensor, np.ndarray], apply_colormap: bool = False,
                                  clusterer=None, **kwargs) -> Union[np.ndarray, Tuple[np.ndarray, np.ndarray]]:
     """(N,H,W,C) features -> (N,H,W) integer masks clustered over all views together [, (N,H,W,3) uint8 colours]
-    (reference misc.py:81-170).  kwargs: eps, min_samples, min_cluster_size.  `clusterer(pixels ndarray [M,C]) -> labels [M]`
-    replaces the HDBSCAN call (for tests and for other clustering back-ends)."""
+    (reference misc.py:81-170).  kwargs: eps, min_samples, min_cluster_size.  HDBSCAN itself runs on the GPU (utils/hdbscan.py:
+    exact core distances and mutual-reachability spanning tree as HIP kernels, the tree walk on the host);
+    `clusterer(pixels ndarray [M,C]) -> labels [M]` replaces it (other clustering back-ends, tests)."""
     if not (isinstance(feature_map, (torch.Tensor, np.ndarray)) and feature_map.ndim == 4):
         raise ValueError("feature_map must be a 4-D tensor or array of shape (N, H, W, C)")
     n, h, w, c = feature_map.shape
     dev = _device(feature_map.device if isinstance(feature_map, torch.Tensor) and feature_map.is_cuda else None)
     pix = _as_device_f32(feature_map, dev).reshape(-1, c).contiguous()
-    host = pix.cpu().numpy()
-    raw = clusterer(host) if clusterer is not None else _hdbscan(host, kwargs.get("eps"), kwargs.get("min_samples"),
-                                                                 kwargs.get("min_cluster_size"))
+    raw = clusterer(pix.cpu().numpy()) if clusterer is not None else _hdbscan(pix, kwargs.get("eps"), kwargs.get("min_samples"),
+                                                                               kwargs.get("min_cluster_size"))
     labels = fill_noise_labels(pix, torch.as_tensor(np.asarray(raw).astype(np.int64)))
     masks = labels.view(n, h, w)
     if not apply_colormap:

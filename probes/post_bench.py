@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--brute-rows", type=int, default=20000, help="rows of the brute-force cross-check (0: skip)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of a host KD-tree query for comparison (0: skip)")
+    ap.add_argument("--hdbscan", action="store_true", help="also time the clustering step (GPU HDBSCAN, demo.py:78-83 parameters)")
     a = ap.parse_args()
     pts, feats = scene(a.views, a.h, a.w, 8, seed=3)
     pts, feats = pts.cuda(), feats.cuda()
@@ -46,6 +47,21 @@ def main():
     lab[torch.rand(M, device="cuda") < 0.3] = -1
     px = smooth.reshape(-1, 8).contiguous()
     res["label_fill_ms"], _ = timed(lambda: misc.fill_noise_labels(px, lab), reps=1)
+    if a.hdbscan:
+        from iggt_official_amd.utils import hdbscan as hd
+
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        eu, ev, ew, core = hd.mutual_reachability_mst(px, 100)
+        torch.cuda.synchronize()
+        res["hdbscan_core_and_spanning_tree_s"] = time.perf_counter() - t
+        t = time.perf_counter()
+        labels = _C.hdbscan_labels_from_mst(eu.cpu().numpy(), ev.cpu().numpy(), ew.cpu().numpy(), M, 500, 0.06, False)
+        res["hdbscan_tree_walk_host_s"] = time.perf_counter() - t
+        res["hdbscan_clusters"], res["hdbscan_noise"] = int(labels.max() + 1), int((labels < 0).sum())
+        t = time.perf_counter()
+        misc.cluster_features_to_masks_mv(smooth, apply_colormap=True, eps=0.06, min_samples=100, min_cluster_size=500)
+        res["cluster_features_to_masks_mv_s"] = time.perf_counter() - t
     if a.brute_rows:
         rows = torch.randperm(M, device="cuda")[: a.brute_rows]
         t = time.perf_counter()

@@ -127,3 +127,94 @@ def test_alias_module_exports():
     import iggt.utils.misc as alias
 
     assert alias.knn_avg_features_pyg is misc.knn_avg_features_pyg and alias.apply_pca_colormap is misc.apply_pca_colormap
+
+
+# ---- HDBSCAN (csrc/hdbscan.hip + csrc/hdbscan_tree.hip, iggt_official_amd/utils/hdbscan.py) ----------------------------------
+def _blobs(rng, n, c, d, spread):
+    cen = rng.normal(size=(c, d)) * 3
+    return np.concatenate([cen[i] + rng.normal(size=(n // c, d)) * spread * (0.5 + i / c) for i in range(c)]).astype(np.float32)
+
+
+@pytest.mark.parametrize("M,C,k", [(1000, 8, 10), (5003, 8, 100), (777, 3, 5), (2000, 16, 128), (300, 8, 1)])
+def test_hdbscan_core_distances(M, C, k):
+    """distance to the k-th nearest row, the row itself counted: sorted brute-force distances in fp64 at column k - 1."""
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, C, generator=g).cuda()
+    x[M // 2] = x[M // 3]                                   # a duplicate pair: distance 0 at k = 2
+    core = _C.hdbscan_core_dist(x, k)
+    ref = torch.sort(torch.cdist(x.double(), x.double()), dim=1).values[:, k - 1]
+    assert torch.allclose(core.double(), ref, rtol=2e-6, atol=1e-6), float((core.double() - ref).abs().max())
+
+
+def test_hdbscan_spanning_tree_and_labels_match_scikit_learn():
+    """The whole estimator on the GPU against scikit-learn's (one of the three the reference accepts): spanning-tree weight equal
+    to scipy's MST of the dense mutual-reachability matrix, partitions equal (ARI), at the demo's parameters too."""
+    from scipy.sparse.csgraph import minimum_spanning_tree
+    from scipy.spatial.distance import cdist
+    from sklearn.cluster import HDBSCAN
+    from sklearn.metrics import adjusted_rand_score
+
+    from iggt_official_amd.utils import hdbscan as hd
+
+    rng = np.random.default_rng(0)
+    cases = [
+        ("blobs", _blobs(rng, 3000, 5, 8, 0.3), dict(min_samples=10, min_cluster_size=40, eps=0.0)),
+        ("blobs eps", _blobs(rng, 3000, 6, 8, 0.4), dict(min_samples=10, min_cluster_size=40, eps=0.5)),
+        ("noisy", np.concatenate([_blobs(rng, 2000, 4, 8, 0.3), rng.uniform(-8, 8, size=(600, 8)).astype(np.float32)]),
+         dict(min_samples=8, min_cluster_size=30, eps=0.0)),
+        ("demo parameters", _blobs(rng, 6000, 4, 8, 0.02), dict(min_samples=100, min_cluster_size=500, eps=0.06)),
+        ("3 channels", rng.uniform(size=(1500, 3)).astype(np.float32), dict(min_samples=5, min_cluster_size=20, eps=0.0)),
+        ("5 channels (padded)", _blobs(rng, 1200, 3, 5, 0.3), dict(min_samples=5, min_cluster_size=30, eps=0.0)),
+    ]
+    for name, X, kw in cases:
+        x = torch.from_numpy(X).cuda()
+        eu, ev, ew, core = hd.mutual_reachability_mst(x, kw["min_samples"])
+        D = cdist(X.astype(np.float64), X.astype(np.float64))
+        cref = np.sort(D, axis=1)[:, kw["min_samples"] - 1]
+        assert np.allclose(core.cpu().numpy(), cref, rtol=3e-6, atol=1e-6), name
+        MR = np.maximum(np.maximum(cref[:, None], cref[None, :]), D)
+        np.fill_diagonal(MR, 0)
+        wref = minimum_spanning_tree(MR).sum()
+        assert abs(float(ew.double().sum()) - wref) < 2e-5 * wref, (name, float(ew.double().sum()), wref)
+        ref = HDBSCAN(min_samples=kw["min_samples"], min_cluster_size=kw["min_cluster_size"], cluster_selection_epsilon=kw["eps"],
+                      algorithm="brute").fit(X.astype(np.float64)).labels_
+        got = hd.hdbscan_labels(x, kw["min_cluster_size"], kw["min_samples"], kw["eps"])
+        ari = adjusted_rand_score(ref, got)
+        from conftest import report
+        report(f"post/hdbscan/{name}", dict(points=len(X), clusters=int(got.max() + 1), clusters_ref=int(ref.max() + 1), ari=ari,
+                                            noise=int((got < 0).sum()), noise_ref=int((ref < 0).sum())))
+        assert got.max() == ref.max() and ari > 0.99, (name, ari)
+
+
+def test_cluster_features_to_masks_mv_runs_hdbscan_on_the_gpu():
+    """reference misc.py:81-170 end to end: HDBSCAN (GPU) -> noise pixels take the nearest labelled pixel's label -> colours.
+    Planted, well separated feature clusters on a 3-view map: every pixel ends in its planted cluster."""
+    rng = np.random.default_rng(1)
+    n, h, w, c = 3, 28, 36, 8
+    cen = rng.normal(size=(4, c)).astype(np.float32) * 2
+    planted = rng.integers(0, 4, size=(n, h, w))
+    fmap = cen[planted] + rng.normal(size=(n, h, w, c)).astype(np.float32) * 0.02
+    masks, colored = misc.cluster_features_to_masks_mv(torch.from_numpy(fmap).cuda(), apply_colormap=True, eps=0.06,
+                                                       min_samples=20, min_cluster_size=100)
+    assert masks.shape == (n, h, w) and colored.shape == (n, h, w, 3) and colored.dtype == np.uint8 and masks.min() >= 0
+    from sklearn.metrics import adjusted_rand_score
+    assert adjusted_rand_score(planted.reshape(-1), masks.reshape(-1)) == 1.0
+
+
+def test_hdbscan_timing_report():
+    """Wall time of the GPU estimator at 50 k and 200 k points of 8 channels (reported, not gated)."""
+    import time
+
+    from conftest import report
+    from iggt_official_amd.utils import hdbscan as hd
+
+    rng = np.random.default_rng(2)
+    for M in (50_000, 200_000):
+        X = _blobs(rng, M, 8, 8, 0.05)
+        x = torch.from_numpy(X).cuda()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = hd.hdbscan_labels(x, 500, 100, 0.06)
+        dt = time.perf_counter() - t0
+        report(f"post/hdbscan/timing_{M}", dict(points=M, seconds=dt, clusters=int(got.max() + 1), noise=int((got < 0).sum())))
+        assert got.max() + 1 == 8
