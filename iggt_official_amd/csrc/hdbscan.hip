@@ -9,9 +9,10 @@
 //                       rounds cannot close a cycle.  The per-component minimum, the hooking and the pointer jumping are a few
 //                       torch index operations per round (iggt_official_amd/utils/hdbscan.py); the M - 1 edges then go to the host
 //                       walk in csrc/hdbscan_tree.hip.
-// Both kernels give one thread a query point (coordinates in registers) and stream all points past it in tiles of 256 staged in
-// LDS, channel-major, so that every lane reads the same candidate (a broadcast, no bank conflict).  Bound: vector ALU --
-// 3 C + 6 operations per pair, no reuse to exploit beyond the LDS tile; M = 1.35 M points (8 views x 504 x 336) is 1.8e12 pairs.
+// Both kernels give a thread its query point(s) (coordinates in registers) and stream all points past them in tiles of 256 staged
+// in LDS, candidate-major, so that every lane reads the same candidate with one or two 16-byte broadcast reads (a first version
+// read it channel by channel: 8 LDS instructions per pair beside 8 FMAs).  Bound: vector ALU -- 3 C + 6 operations per pair, no
+// reuse to exploit beyond the LDS tile; M = 1.35 M points (8 views x 504 x 336) is 1.8e12 pairs per pass.
 //   * core distances keep the k smallest squared distances of a query in LDS, slot-major ([k][256]: lane t owns column t), with
 //     the current maximum and its slot in registers; a candidate below the maximum replaces it and the column is rescanned
 //     (k reads).  Replacements become rare quickly (~k ln(M / k) per query), the scan over candidates dominates.
@@ -27,10 +28,25 @@ namespace {
 constexpr int TILE = 256;
 constexpr int KMAX = 128;
 
+// C floats of one staged candidate -> registers (all lanes read the same address: LDS broadcast)
+template <int C>
+IGGT_DEVINL void load_point(const float* src, float (&p)[C]) {
+    if constexpr (C % 4 == 0) {
+#pragma unroll
+        for (int v = 0; v < C / 4; ++v) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(src + 4 * v);
+            p[4 * v] = w[0]; p[4 * v + 1] = w[1]; p[4 * v + 2] = w[2]; p[4 * v + 3] = w[3];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) p[c] = src[c];
+    }
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void hdb_core_dist_kernel(const float* __restrict__ x, long M, int k, float* __restrict__ core) {
-    extern __shared__ float smem[];
-    float* tile = smem;                 // [C][TILE]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tile = smem;                 // [TILE][C]: a candidate's C coordinates are contiguous (one or two 16-byte broadcast reads)
     float* best = smem + C * TILE;      // [k][TILE]
     const int t = threadIdx.x;
     const long i = (long)blockIdx.x * TILE + t;
@@ -45,15 +61,17 @@ __global__ __launch_bounds__(256) void hdb_core_dist_kernel(const float* __restr
         {
             const long j = j0 + t;
 #pragma unroll
-            for (int c = 0; c < C; ++c) tile[c * TILE + t] = j < M ? x[j * C + c] : INFINITY;   // padding: distance inf
+            for (int c = 0; c < C; ++c) tile[t * C + c] = j < M ? x[j * C + c] : INFINITY;   // padding: distance inf
         }
         __syncthreads();
         const int nj = (int)((M - j0) < TILE ? (M - j0) : TILE);
         for (int jj = 0; jj < nj; ++jj) {
+            float p[C];
+            load_point<C>(tile + jj * C, p);
             float d2 = 0.f;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const float d = q[c] - tile[c * TILE + jj];
+                const float d = q[c] - p[c];
                 d2 = fmaf(d, d, d2);
             }
             if (d2 < cur_max) {          // replace the current maximum, find the new one
@@ -78,27 +96,42 @@ __global__ __launch_bounds__(256) void hdb_core_dist_kernel(const float* __restr
 // One Boruvka round.  x, core2 (= core^2), comp, idx are given in an order sorted by component; idx[p] = original index of the
 // point at position p (ties are broken on ORIGINAL indices).  tile_lo / tile_hi: smallest / largest component id inside each tile
 // of 256 positions.  Output per position: best_w2 (squared mutual reachability, inf if none), best_p (position of the partner, -1).
+// Every thread owns QPT = 2 queries (positions base + t and base + 256 + t of a 512-position block): a staged candidate is read
+// from LDS once for two pairs.
+constexpr int QPT = 2;
+
 template <int C>
 __global__ __launch_bounds__(256) void hdb_nearest_foreign_kernel(const float* __restrict__ x, const float* __restrict__ core2,
                                                                   const int* __restrict__ comp, const int* __restrict__ idx,
                                                                   const int* __restrict__ tile_lo, const int* __restrict__ tile_hi,
                                                                   long M, float* __restrict__ best_w2, int* __restrict__ best_p) {
-    __shared__ float tile[C][TILE];
+    __shared__ __attribute__((aligned(16))) float tile[TILE * C];
     __shared__ float tcore[TILE];
     __shared__ int tcomp[TILE], tidx[TILE];
     const int t = threadIdx.x;
-    const long i = (long)blockIdx.x * TILE + t;
-    const bool live = i < M;
-    float q[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) q[c] = live ? x[i * C + c] : 0.f;
-    const float qc2 = live ? core2[i] : 0.f;
-    const int qcomp = live ? comp[i] : -1, qidx = live ? idx[i] : 0;
-    // all queries of this workgroup in one component?  (positions are sorted by component)
-    const int wg_lo = tile_lo[blockIdx.x], wg_hi = tile_hi[blockIdx.x];
-    float bw = INFINITY;
-    int bp = -1, blo = 0x7fffffff, bhi = 0x7fffffff;
     const int ntiles = (int)((M + TILE - 1) / TILE);
+    float q[QPT][C], qc2[QPT], bw[QPT];
+    int qcomp[QPT], qidx[QPT], bp[QPT], blo[QPT], bhi[QPT];
+    bool live[QPT];
+    int wg_lo = 0x7fffffff, wg_hi = -1;                 // component range of all queries of this workgroup
+#pragma unroll
+    for (int u = 0; u < QPT; ++u) {
+        const long i = ((long)blockIdx.x * QPT + u) * TILE + t;
+        live[u] = i < M;
+#pragma unroll
+        for (int c = 0; c < C; ++c) q[u][c] = live[u] ? x[i * C + c] : 0.f;
+        qc2[u] = live[u] ? core2[i] : 0.f;
+        qcomp[u] = live[u] ? comp[i] : -1;
+        qidx[u] = live[u] ? idx[i] : 0;
+        bw[u] = INFINITY;
+        bp[u] = -1;
+        blo[u] = bhi[u] = 0x7fffffff;
+        const int qt = blockIdx.x * QPT + u;
+        if (qt < ntiles) {
+            wg_lo = tile_lo[qt] < wg_lo ? tile_lo[qt] : wg_lo;
+            wg_hi = tile_hi[qt] > wg_hi ? tile_hi[qt] : wg_hi;
+        }
+    }
     for (int tl = 0; tl < ntiles; ++tl) {
         // skip a tile that lies entirely inside the single component all queries here belong to (block-uniform test)
         if (wg_lo == wg_hi && tile_lo[tl] == wg_lo && tile_hi[tl] == wg_lo) continue;
@@ -108,37 +141,47 @@ __global__ __launch_bounds__(256) void hdb_nearest_foreign_kernel(const float* _
             const long j = j0 + t;
             const bool ok = j < M;
 #pragma unroll
-            for (int c = 0; c < C; ++c) tile[c][t] = ok ? x[j * C + c] : 0.f;
+            for (int c = 0; c < C; ++c) tile[t * C + c] = ok ? x[j * C + c] : 0.f;
             tcore[t] = ok ? core2[j] : INFINITY;
             tcomp[t] = ok ? comp[j] : -1;
             tidx[t] = ok ? idx[j] : 0;
         }
         __syncthreads();
-        if (!live) continue;
         const int nj = (int)((M - j0) < TILE ? (M - j0) : TILE);
         for (int jj = 0; jj < nj; ++jj) {
-            if (tcomp[jj] == qcomp) continue;
-            float d2 = 0.f;
+            float p[C];
+            load_point<C>(tile + jj * C, p);
+            const float pc2 = tcore[jj];
+            const int pcomp = tcomp[jj];
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const float d = q[c] - tile[c][jj];
-                d2 = fmaf(d, d, d2);
-            }
-            const float w = fmaxf(fmaxf(qc2, tcore[jj]), d2);
-            if (w > bw) continue;
-            const int oj = tidx[jj];
-            const int lo = qidx < oj ? qidx : oj, hi = qidx < oj ? oj : qidx;
-            if (w < bw || lo < blo || (lo == blo && hi < bhi)) {
-                bw = w;
-                bp = (int)(j0 + jj);
-                blo = lo;
-                bhi = hi;
+            for (int u = 0; u < QPT; ++u) {
+                if (pcomp == qcomp[u] || !live[u]) continue;
+                float d2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float d = q[u][c] - p[c];
+                    d2 = fmaf(d, d, d2);
+                }
+                const float w = fmaxf(fmaxf(qc2[u], pc2), d2);
+                if (w > bw[u]) continue;
+                const int oj = tidx[jj];
+                const int lo = qidx[u] < oj ? qidx[u] : oj, hi = qidx[u] < oj ? oj : qidx[u];
+                if (w < bw[u] || lo < blo[u] || (lo == blo[u] && hi < bhi[u])) {
+                    bw[u] = w;
+                    bp[u] = (int)(j0 + jj);
+                    blo[u] = lo;
+                    bhi[u] = hi;
+                }
             }
         }
     }
-    if (live) {
-        best_w2[i] = bw;
-        best_p[i] = bp;
+#pragma unroll
+    for (int u = 0; u < QPT; ++u) {
+        const long i = ((long)blockIdx.x * QPT + u) * TILE + t;
+        if (live[u]) {
+            best_w2[i] = bw[u];
+            best_p[i] = bp[u];
+        }
     }
 }
 
@@ -176,7 +219,7 @@ extern "C" int iggt_hdbscan_nearest_foreign_f32(const float* x, const float* cor
     if (x == nullptr || core2 == nullptr || comp == nullptr || idx == nullptr || tile_lo == nullptr || tile_hi == nullptr ||
         best_w2 == nullptr || best_p == nullptr || M <= 0 || M >= (1L << 31))
         return -1;
-    const dim3 grid((unsigned)((M + TILE - 1) / TILE)), block(TILE);
+    const dim3 grid((unsigned)((M + QPT * TILE - 1) / (QPT * TILE))), block(TILE);
     hipStream_t st = (hipStream_t)stream;
     if (C == 8) hipLaunchKernelGGL(hdb_nearest_foreign_kernel<8>, grid, block, 0, st, x, core2, comp, idx, tile_lo, tile_hi, M, best_w2, best_p);
     else if (C == 3) hipLaunchKernelGGL(hdb_nearest_foreign_kernel<3>, grid, block, 0, st, x, core2, comp, idx, tile_lo, tile_hi, M, best_w2, best_p);
