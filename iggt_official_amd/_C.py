@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -115,8 +115,8 @@ _SIGNATURES = {
     "iggt_track_tokens_f32": [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_long, _c_int, _c_void_p, _c_long,
                               _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_float, _c_void_p],
     "iggt_track_update_f32": [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_int, _c_int, _c_float, _c_void_p],
-    "iggt_hdbscan_core_dist_f32": [_c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p],
-    "iggt_hdbscan_nearest_foreign_f32": [_c_void_p] * 6 + [_c_long, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "iggt_hdbscan_core_dist_f32": [_c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+    "iggt_hdbscan_nearest_foreign_f32": [_c_void_p] * 8 + [_c_long, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "iggt_hdbscan_labels_from_mst": [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, ctypes.c_double, _c_int, _c_void_p],
     "iggt_write_special_tokens": [_c_void_p, _c_long, _c_long, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_void_p],
@@ -887,17 +887,29 @@ def track_update(coords, delta, pred, stride):
 
 # ------------------------------------------------------------------------------------------------
 # HDBSCAN (csrc/hdbscan.hip, csrc/hdbscan_tree.hip)
-def hdbscan_core_dist(x, k):
-    """x fp32 [M, C] (device, C in {3, 8, 16}) -> core distances fp32 [M]: distance to the k-th nearest row, itself counted."""
+def hdbscan_tile_boxes(x):
+    """x fp32 [M, C] -> (box_lo, box_hi) fp32 [ceil(M / 256), C]: per-channel extent of every tile of 256 consecutive rows."""
+    M, C = x.shape
+    nt = (M + 255) // 256
+    pad = torch.cat([x, x[-1:].expand(nt * 256 - M, C)]).view(nt, 256, C)
+    return pad.amin(1).contiguous(), pad.amax(1).contiguous()
+
+
+def hdbscan_core_dist(x, k, boxes=None):
+    """x fp32 [M, C] (device, C in {3, 8, 16}) -> core distances fp32 [M]: distance to the k-th nearest row, itself counted.
+    boxes: hdbscan_tile_boxes(x) if already known."""
     _dev(x)
     _f32_all(x)
     M, C = x.shape
+    lo, hi = boxes if boxes is not None else hdbscan_tile_boxes(x)
+    _f32_all(lo, hi)
     core = torch.empty(M, dtype=torch.float32, device=x.device)
-    _check(load().iggt_hdbscan_core_dist_f32(x.data_ptr(), M, C, int(k), core.data_ptr(), _stream()), "iggt_hdbscan_core_dist_f32")
+    _check(load().iggt_hdbscan_core_dist_f32(x.data_ptr(), M, C, int(k), lo.data_ptr(), hi.data_ptr(), core.data_ptr(), _stream()),
+           "iggt_hdbscan_core_dist_f32")
     return core
 
 
-def hdbscan_nearest_foreign(x, core2, comp, idx, tile_lo, tile_hi):
+def hdbscan_nearest_foreign(x, core2, comp, idx, tile_lo, tile_hi, boxes=None):
     """One Boruvka round (include/iggt_hip.h): arrays ordered by component -> (best_w2 fp32 [M], best_p int32 [M])."""
     _dev(x, core2, comp, idx, tile_lo, tile_hi)
     _f32_all(x, core2)
@@ -905,10 +917,13 @@ def hdbscan_nearest_foreign(x, core2, comp, idx, tile_lo, tile_hi):
     for t in (comp, idx, tile_lo, tile_hi):
         assert t.dtype == torch.int32 and t.is_contiguous()
     assert tile_lo.numel() == (M + 255) // 256 == tile_hi.numel()
+    lo, hi = boxes if boxes is not None else hdbscan_tile_boxes(x)
+    _f32_all(lo, hi)
     w2 = torch.empty(M, dtype=torch.float32, device=x.device)
     bp = torch.empty(M, dtype=torch.int32, device=x.device)
     rc = load().iggt_hdbscan_nearest_foreign_f32(x.data_ptr(), core2.data_ptr(), comp.data_ptr(), idx.data_ptr(), tile_lo.data_ptr(),
-                                                 tile_hi.data_ptr(), M, C, w2.data_ptr(), bp.data_ptr(), _stream())
+                                                 tile_hi.data_ptr(), lo.data_ptr(), hi.data_ptr(), M, C, w2.data_ptr(), bp.data_ptr(),
+                                                 _stream())
     _check(rc, "iggt_hdbscan_nearest_foreign_f32")
     return w2, bp
 

@@ -13,11 +13,15 @@
 // in LDS, candidate-major, so that every lane reads the same candidate with one or two 16-byte broadcast reads (a first version
 // read it channel by channel: 8 LDS instructions per pair beside 8 FMAs).  Bound: vector ALU -- 3 C + 6 operations per pair, no
 // reuse to exploit beyond the LDS tile; M = 1.35 M points (8 views x 504 x 336) is 1.8e12 pairs per pass.
-//   * core distances keep the k smallest squared distances of a query in LDS, slot-major ([k][256]: lane t owns column t), with
-//     the current maximum and its slot in registers; a candidate below the maximum replaces it and the column is rescanned
-//     (k reads).  Replacements become rare quickly (~k ln(M / k) per query), the scan over candidates dominates.
+//   * core distances keep the k smallest squared distances of a query in LDS as a max-heap, node-major ([k][256]: lane t owns
+//     column t); a candidate below the root replaces it and sifts down (log2 k steps).  (First version: unsorted slots, rescanned
+//     on every replacement -- 5.9 s of the 6.5 s the pass took at k = 100 and 1.35 M points, against 0.6 s at k = 5.)
 //   * nearest foreign: points arrive SORTED BY COMPONENT; a tile whose 256 points all belong to the component of every query of
 //     the workgroup is skipped, so that once a giant component has formed a round costs ~2 |giant| |rest| pairs instead of M^2.
+//   * both: the points are ordered along a Morton curve over their first three principal axes and every 256-point tile carries its
+//     bounding box; tiles are visited outward from the query tile and one whose box lies farther away than every query's current
+//     bound is skipped after a block-wide vote -- exact (the box gap is a lower bound of every pair distance), and what turns
+//     the M^2 passes into a neighbourhood search on data that is not uniformly spread in all C dimensions.
 #include <math.h>
 
 #include "common.h"
@@ -43,21 +47,53 @@ IGGT_DEVINL void load_point(const float* src, float (&p)[C]) {
     }
 }
 
+// squared distance between two axis-aligned boxes (lower bound of every point-pair distance across them); all arguments are
+// workgroup-uniform, so this is scalar work
 template <int C>
-__global__ __launch_bounds__(256) void hdb_core_dist_kernel(const float* __restrict__ x, long M, int k, float* __restrict__ core) {
+IGGT_DEVINL float box_gap2(const float* __restrict__ alo, const float* __restrict__ ahi, const float* __restrict__ blo,
+                           const float* __restrict__ bhi) {
+    float g2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float g = fmaxf(fmaxf(alo[c] - bhi[c], blo[c] - ahi[c]), 0.f);
+        g2 = fmaf(g, g, g2);
+    }
+    return g2;
+}
+
+// tiles in the order own, own + 1, own - 1, own + 2, ...: points are sorted along a space-filling curve, so the nearest tiles
+// come first and tighten the bounds that let the far ones be skipped.  step in [0, 2 * ntiles); -1: outside
+IGGT_DEVINL int outward_tile(int own, int step, int ntiles) {
+    const int m = (step + 1) >> 1;
+    const int tl = (step & 1) ? own + m : own - m;
+    return (tl < 0 || tl >= ntiles) ? -1 : tl;
+}
+
+// Points are given SORTED along a Morton curve over their first three principal axes (iggt_official_amd/utils/hdbscan.py), with the
+// bounding box of every 256-point tile (box_lo / box_hi [ntiles][C]).  A candidate tile whose box is farther from the query tile's
+// box than every query's current k-th distance cannot change any result and is skipped (block-wide vote, exact).
+template <int C>
+__global__ __launch_bounds__(256) void hdb_core_dist_kernel(const float* __restrict__ x, long M, int k,
+                                                            const float* __restrict__ box_lo, const float* __restrict__ box_hi,
+                                                            float* __restrict__ core) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem;                 // [TILE][C]: a candidate's C coordinates are contiguous (one or two 16-byte broadcast reads)
-    float* best = smem + C * TILE;      // [k][TILE]
+    float* heap = smem + C * TILE;      // [k][TILE]: per-query max-heap of the k smallest squared distances, node-major
     const int t = threadIdx.x;
-    const long i = (long)blockIdx.x * TILE + t;
+    const int own = blockIdx.x;
+    const int ntiles = (int)((M + TILE - 1) / TILE);
+    const long i = (long)own * TILE + t;
     float q[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) q[c] = i < M ? x[i * C + c] : 0.f;
-    for (int s = 0; s < k; ++s) best[s * TILE + t] = INFINITY;
-    float cur_max = INFINITY;
-    int cur_slot = 0;
-    for (long j0 = 0; j0 < M; j0 += TILE) {
-        __syncthreads();
+    for (int s = 0; s < k; ++s) heap[s * TILE + t] = INFINITY;
+    float cur_max = i < M ? INFINITY : -1.f;     // dead lanes never ask for a tile
+    for (int step = 0; step < 2 * ntiles; ++step) {
+        const int tl = outward_tile(own, step, ntiles);
+        if (tl < 0) continue;
+        const float gap2 = box_gap2<C>(box_lo + (long)own * C, box_hi + (long)own * C, box_lo + (long)tl * C, box_hi + (long)tl * C);
+        if (!__syncthreads_or(gap2 < cur_max)) continue;      // (also the barrier that protects the previous tile's readers)
+        const long j0 = (long)tl * TILE;
         {
             const long j = j0 + t;
 #pragma unroll
@@ -74,36 +110,42 @@ __global__ __launch_bounds__(256) void hdb_core_dist_kernel(const float* __restr
                 const float d = q[c] - p[c];
                 d2 = fmaf(d, d, d2);
             }
-            if (d2 < cur_max) {          // replace the current maximum, find the new one
-                best[cur_slot * TILE + t] = d2;
-                float m = -1.f;
-                int ms = 0;
-                for (int s = 0; s < k; ++s) {
-                    const float v = best[s * TILE + t];
-                    if (v > m) {
-                        m = v;
-                        ms = s;
-                    }
+            if (d2 < cur_max) {          // replace the root of the max-heap and sift down
+                int n = 0;
+                for (;;) {
+                    const int l = 2 * n + 1;
+                    if (l >= k) break;
+                    const float lv = heap[l * TILE + t];
+                    const float rv = (l + 1 < k) ? heap[(l + 1) * TILE + t] : -1.f;
+                    const int cn = rv > lv ? l + 1 : l;
+                    const float cv = fmaxf(lv, rv);
+                    if (cv <= d2) break;
+                    heap[n * TILE + t] = cv;
+                    n = cn;
                 }
-                cur_max = m;
-                cur_slot = ms;
+                heap[n * TILE + t] = d2;
+                cur_max = heap[t];
             }
         }
     }
     if (i < M) core[i] = sqrtf(cur_max);   // inf when M < k: fewer than k points exist
 }
 
-// One Boruvka round.  x, core2 (= core^2), comp, idx are given in an order sorted by component; idx[p] = original index of the
-// point at position p (ties are broken on ORIGINAL indices).  tile_lo / tile_hi: smallest / largest component id inside each tile
-// of 256 positions.  Output per position: best_w2 (squared mutual reachability, inf if none), best_p (position of the partner, -1).
+// One Boruvka round.  x, core2 (= core^2), comp, idx are given in an order sorted by component (and spatially inside a component);
+// idx[p] = index of the point at position p in the caller's numbering (ties are broken on those).  tile_lo / tile_hi: smallest /
+// largest component id inside each tile of 256 positions; box_lo / box_hi [ntiles][C]: bounding boxes of the tiles.
+// Output per position: best_w2 (squared mutual reachability, inf if none), best_p (position of the partner, -1).
 // Every thread owns QPT = 2 queries (positions base + t and base + 256 + t of a 512-position block): a staged candidate is read
-// from LDS once for two pairs.
+// from LDS once for two pairs.  Skipped: tiles inside the one component all queries of the workgroup belong to, and tiles whose
+// box is farther from the queries' box than every query's best weight so far (mr >= distance >= box gap; strict, so that an
+// equal-weight candidate can still win the index tie-break).
 constexpr int QPT = 2;
 
 template <int C>
 __global__ __launch_bounds__(256) void hdb_nearest_foreign_kernel(const float* __restrict__ x, const float* __restrict__ core2,
                                                                   const int* __restrict__ comp, const int* __restrict__ idx,
                                                                   const int* __restrict__ tile_lo, const int* __restrict__ tile_hi,
+                                                                  const float* __restrict__ box_lo, const float* __restrict__ box_hi,
                                                                   long M, float* __restrict__ best_w2, int* __restrict__ best_p) {
     __shared__ __attribute__((aligned(16))) float tile[TILE * C];
     __shared__ float tcore[TILE];
@@ -114,6 +156,12 @@ __global__ __launch_bounds__(256) void hdb_nearest_foreign_kernel(const float* _
     int qcomp[QPT], qidx[QPT], bp[QPT], blo[QPT], bhi[QPT];
     bool live[QPT];
     int wg_lo = 0x7fffffff, wg_hi = -1;                 // component range of all queries of this workgroup
+    float qlo[C], qhi[C];                               // their bounding box (workgroup-uniform)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        qlo[c] = INFINITY;
+        qhi[c] = -INFINITY;
+    }
 #pragma unroll
     for (int u = 0; u < QPT; ++u) {
         const long i = ((long)blockIdx.x * QPT + u) * TILE + t;
@@ -123,20 +171,29 @@ __global__ __launch_bounds__(256) void hdb_nearest_foreign_kernel(const float* _
         qc2[u] = live[u] ? core2[i] : 0.f;
         qcomp[u] = live[u] ? comp[i] : -1;
         qidx[u] = live[u] ? idx[i] : 0;
-        bw[u] = INFINITY;
+        bw[u] = live[u] ? INFINITY : -1.f;
         bp[u] = -1;
         blo[u] = bhi[u] = 0x7fffffff;
         const int qt = blockIdx.x * QPT + u;
         if (qt < ntiles) {
             wg_lo = tile_lo[qt] < wg_lo ? tile_lo[qt] : wg_lo;
             wg_hi = tile_hi[qt] > wg_hi ? tile_hi[qt] : wg_hi;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                qlo[c] = fminf(qlo[c], box_lo[(long)qt * C + c]);
+                qhi[c] = fmaxf(qhi[c], box_hi[(long)qt * C + c]);
+            }
         }
     }
-    for (int tl = 0; tl < ntiles; ++tl) {
+    const int own = blockIdx.x * QPT;
+    for (int step = 0; step < 2 * ntiles; ++step) {
+        const int tl = outward_tile(own, step, ntiles);
+        if (tl < 0) continue;
         // skip a tile that lies entirely inside the single component all queries here belong to (block-uniform test)
         if (wg_lo == wg_hi && tile_lo[tl] == wg_lo && tile_hi[tl] == wg_lo) continue;
+        const float gap2 = box_gap2<C>(qlo, qhi, box_lo + (long)tl * C, box_hi + (long)tl * C);
+        if (!__syncthreads_or(gap2 <= bw[0] || gap2 <= bw[1])) continue;
         const long j0 = (long)tl * TILE;
-        __syncthreads();
         {
             const long j = j0 + t;
             const bool ok = j < M;
@@ -186,7 +243,7 @@ __global__ __launch_bounds__(256) void hdb_nearest_foreign_kernel(const float* _
 }
 
 template <int C>
-int launch_core(const float* x, long M, int k, float* core, hipStream_t stream) {
+int launch_core(const float* x, long M, int k, const float* box_lo, const float* box_hi, float* core, hipStream_t stream) {
     const size_t lds = (size_t)(C + k) * TILE * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -195,18 +252,21 @@ int launch_core(const float* x, long M, int k, float* core, hipStream_t stream) 
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(hdb_core_dist_kernel<C>, dim3((unsigned)((M + TILE - 1) / TILE)), dim3(TILE), lds, stream, x, M, k, core);
+    hipLaunchKernelGGL(hdb_core_dist_kernel<C>, dim3((unsigned)((M + TILE - 1) / TILE)), dim3(TILE), lds, stream, x, M, k, box_lo,
+                       box_hi, core);
     return 0;
 }
 
 }  // namespace
 
-extern "C" int iggt_hdbscan_core_dist_f32(const float* x, long M, int C, int k, float* core, void* stream) {
-    if (x == nullptr || core == nullptr || M <= 0 || k < 1 || k > KMAX) return -1;
+extern "C" int iggt_hdbscan_core_dist_f32(const float* x, long M, int C, int k, const float* box_lo, const float* box_hi,
+                                          float* core, void* stream) {
+    if (x == nullptr || core == nullptr || box_lo == nullptr || box_hi == nullptr || M <= 0 || M >= (1L << 31) || k < 1 || k > KMAX)
+        return -1;
     int rc;
-    if (C == 8) rc = launch_core<8>(x, M, k, core, (hipStream_t)stream);
-    else if (C == 3) rc = launch_core<3>(x, M, k, core, (hipStream_t)stream);
-    else if (C == 16) rc = launch_core<16>(x, M, k, core, (hipStream_t)stream);
+    if (C == 8) rc = launch_core<8>(x, M, k, box_lo, box_hi, core, (hipStream_t)stream);
+    else if (C == 3) rc = launch_core<3>(x, M, k, box_lo, box_hi, core, (hipStream_t)stream);
+    else if (C == 16) rc = launch_core<16>(x, M, k, box_lo, box_hi, core, (hipStream_t)stream);
     else return -2;
     if (rc) return rc;
     IGGT_CHECK_LAUNCH();
@@ -214,16 +274,16 @@ extern "C" int iggt_hdbscan_core_dist_f32(const float* x, long M, int C, int k, 
 }
 
 extern "C" int iggt_hdbscan_nearest_foreign_f32(const float* x, const float* core2, const int* comp, const int* idx,
-                                                const int* tile_lo, const int* tile_hi, long M, int C, float* best_w2,
-                                                int* best_p, void* stream) {
+                                                const int* tile_lo, const int* tile_hi, const float* box_lo,
+                                                const float* box_hi, long M, int C, float* best_w2, int* best_p, void* stream) {
     if (x == nullptr || core2 == nullptr || comp == nullptr || idx == nullptr || tile_lo == nullptr || tile_hi == nullptr ||
-        best_w2 == nullptr || best_p == nullptr || M <= 0 || M >= (1L << 31))
+        box_lo == nullptr || box_hi == nullptr || best_w2 == nullptr || best_p == nullptr || M <= 0 || M >= (1L << 31))
         return -1;
     const dim3 grid((unsigned)((M + QPT * TILE - 1) / (QPT * TILE))), block(TILE);
     hipStream_t st = (hipStream_t)stream;
-    if (C == 8) hipLaunchKernelGGL(hdb_nearest_foreign_kernel<8>, grid, block, 0, st, x, core2, comp, idx, tile_lo, tile_hi, M, best_w2, best_p);
-    else if (C == 3) hipLaunchKernelGGL(hdb_nearest_foreign_kernel<3>, grid, block, 0, st, x, core2, comp, idx, tile_lo, tile_hi, M, best_w2, best_p);
-    else if (C == 16) hipLaunchKernelGGL(hdb_nearest_foreign_kernel<16>, grid, block, 0, st, x, core2, comp, idx, tile_lo, tile_hi, M, best_w2, best_p);
+    if (C == 8) hipLaunchKernelGGL(hdb_nearest_foreign_kernel<8>, grid, block, 0, st, x, core2, comp, idx, tile_lo, tile_hi, box_lo, box_hi, M, best_w2, best_p);
+    else if (C == 3) hipLaunchKernelGGL(hdb_nearest_foreign_kernel<3>, grid, block, 0, st, x, core2, comp, idx, tile_lo, tile_hi, box_lo, box_hi, M, best_w2, best_p);
+    else if (C == 16) hipLaunchKernelGGL(hdb_nearest_foreign_kernel<16>, grid, block, 0, st, x, core2, comp, idx, tile_lo, tile_hi, box_lo, box_hi, M, best_w2, best_p);
     else return -2;
     IGGT_CHECK_LAUNCH();
     return 0;

@@ -394,15 +394,20 @@ int iggt_track_update_f32(float* coords, const float* delta, long ldd, float* pr
 
 /* ---- HDBSCAN behind cluster_features_to_masks_mv (iggt/utils/misc.py:81-170; the library call at misc.py:123-129) ----------------
  * core[i] = Euclidean distance from x[i] to its k-th nearest row of x [M][C] (fp32, C in {3, 8, 16}), the row itself counted
- * (k = min_samples <= 128): `NearestNeighbors(n_neighbors=min_samples).kneighbors(X)[0][:, -1]` of the reference's clusterer. */
-int iggt_hdbscan_core_dist_f32(const float* x, long M, int C, int k, float* core, void* stream);
+ * (k = min_samples <= 128): `NearestNeighbors(n_neighbors=min_samples).kneighbors(X)[0][:, -1]` of the reference's clusterer.
+ * box_lo / box_hi [ceil(M / 256)][C]: per-channel minimum / maximum of every tile of 256 consecutive rows -- any row order gives
+ * the exact result; an order that keeps near rows together (a space-filling curve) lets far tiles be skipped. */
+int iggt_hdbscan_core_dist_f32(const float* x, long M, int C, int k, const float* box_lo, const float* box_hi, float* core,
+                               void* stream);
 /* One Boruvka round of the minimum spanning tree of the mutual-reachability graph max(core_i, core_j, |x_i - x_j|).  All arrays
  * are ordered by component id: x [M][C], core2 [M] (= core^2), comp [M], idx [M] (original index of the point at each position:
  * ties are broken on (min, max) of the ORIGINAL indices), tile_lo / tile_hi [ceil(M / 256)] (smallest / largest component id inside
- * each 256-position tile).  Writes, per position, the squared weight best_w2 (inf: no other component) and the POSITION best_p of
- * the cheapest partner outside its own component (-1: none). */
+ * each 256-position tile), box_lo / box_hi [ceil(M / 256)][C] (bounding boxes of the tiles, as above).  Writes, per position, the
+ * squared weight best_w2 (inf: no other component) and the POSITION best_p of the cheapest partner outside its own component
+ * (-1: none). */
 int iggt_hdbscan_nearest_foreign_f32(const float* x, const float* core2, const int* comp, const int* idx, const int* tile_lo,
-                                     const int* tile_hi, long M, int C, float* best_w2, int* best_p, void* stream);
+                                     const int* tile_hi, const float* box_lo, const float* box_hi, long M, int C,
+                                     float* best_w2, int* best_p, void* stream);
 /* HOST function (no GPU needed): spanning tree edges (eu[e], ev[e], ew[e]), e < n_points - 1, of the mutual-reachability graph
  * -> flat HDBSCAN labels [n_points] (-1 = noise; clusters numbered like scikit-learn's): single-linkage dendrogram, condensed
  * tree for min_cluster_size, excess-of-mass selection, cluster_selection_epsilon, allow_single_cluster.  Returns 0, or a

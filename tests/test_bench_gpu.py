@@ -64,3 +64,18 @@ def test_bench_self_launches_its_ranks():
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "view-shard x2" and d["output_check"]["ok"]
+
+
+def test_bench_emulated_rank_line():
+    """`--emulate-world W` (developer mode): one middle rank of a W-GPU run on this GPU as a bench-shaped record -- hipGraph
+    segments on, per-rank attention shape in the roofline entry, no output check (the other ranks' keys are copies)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--views", "8", "--emulate-world", "4", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, cwd=ROOT, timeout=900,
+                         env=dict(os.environ, IGGT_BENCH_BF16_LEG="0"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    e = d["emulated_rank"]
+    assert d["n_gpus"] == 1 and d["graphs"] is True and e["world"] == 4 and e["rank"] == 2 and e["views_of_this_rank"] == 2
+    assert "output_check" not in d and "cpu_baseline" not in d
+    assert abs(d["roofline"]["flops_per_launch"] - 4.0 * (2 * 1374) * (8 * 1374) * 1024) < 1.0
+    assert abs(e["job_views_per_s_if_transport_were_free"] - 4 * d["value"]) < 1e-6 * d["value"] * 4 + 1e-9

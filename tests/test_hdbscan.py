@@ -64,12 +64,12 @@ def test_host_walk_matches_the_oracle(single):
     assert _C.hdbscan_labels_from_mst(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), 1, 2).tolist() == [-1]
 
 
-def _core_dist_torch(x, k):
+def _core_dist_torch(x, k, boxes=None):
     d = torch.cdist(x.double(), x.double())
     return torch.sort(d, dim=1).values[:, k - 1].float()
 
 
-def _nearest_foreign_torch(xs, core2, comp, idx, tile_lo, tile_hi):
+def _nearest_foreign_torch(xs, core2, comp, idx, tile_lo, tile_hi, boxes=None):
     """Re-statement of hdb_nearest_foreign_kernel: squared mutual reachability in fp32, ties on (min, max) original index."""
     M = xs.shape[0]
     diff = xs[:, None, :] - xs[None, :, :]
