@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -478,7 +478,8 @@ def conv2d_nhwc(x, w_hi, w_lo, bias, y, *, KH, KW, stride=1, pad_y=0, pad_x=0, H
     cout_phys = Cout if cout_phys is None else cout_phys
     Ho = Hout if Ho is None else Ho
     Wo = Wout if Wo is None else Wo
-    assert w_hi.dtype == torch.bfloat16 and w_hi.is_contiguous() and w_hi.shape[1] == KH * KW * Cin
+    assert w_hi.dtype == (torch.float16 if prec == 2 else torch.bfloat16) and w_hi.is_contiguous()
+    assert w_hi.shape[1] == KH * KW * Cin and (w_lo is None or (w_lo.dtype == torch.bfloat16 and w_lo.shape == w_hi.shape))
     ws = _conv_ws(x.device)
     rc = load().iggt_conv2d_nhwc_f32_ws(x.data_ptr(), ldx, w_hi.data_ptr(), _ptr(w_lo), _ptr(bias), _ptr(res),
                                         _ptr(res2), 0 if res is None else res.shape[3], y.data_ptr(), ldy, N, Hi, Wi, Cin, Ho,

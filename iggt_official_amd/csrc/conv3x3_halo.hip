@@ -18,6 +18,9 @@
 // 16 consecutive pixels (the key only depends on the pixel index, so a tap shift just moves the run).
 // Same numerics as conv_igemm PREC = 3 (split-bf16, three MFMAs per product, fp32 accumulate) and the same fused
 // ReLU-on-load / bias / activation / residual epilogue; tests/test_conv_gpu.py runs every case through both kernels.
+// PREC = 2: activations fp16 hi + fp16 lo (exact to 2^-22), weights rounded once to fp16 -- ONE weight plane (half the DMA
+// and ring), two MFMAs per product; the mean response to the weight rounding comes back through the nine border-class
+// correction vectors of conv_meancomp.hip, which the epilogue adds in place of the bias.
 #include <stdlib.h>
 
 #include "common.h"
@@ -29,6 +32,7 @@ struct HaloParams {
     const bf16_t* w_hi;
     const bf16_t* w_lo;
     const float* bias;
+    const float* corr;   // PREC == 2: [9][Cout] bias + mean-input correction per border class (conv_meancomp.hip)
     const float* res;
     const float* res2;
     float* y;
@@ -61,20 +65,26 @@ IGGT_DEVINL void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, int TWD>
+template <int BN, int TWD, int PREC, bool PIPE>
 struct HaloTile {
     using S = TileShape<TWD>;
     static constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N, MI = 8 / WAVES_M;   // 8 row blocks of 32 pixels
-    static constexpr int W_STAGE = 2 * BN * 64;                     // hi + lo rows of one (tap, slice)
-    static constexpr int NI = W_STAGE / (512 * 16);                 // DMA instructions per thread and step
+    // PREC = 2 has one weight plane: a whole kernel ROW (3 taps) fits a stage, in a two-deep ring -- a third of the barriers
+    static constexpr int TPS = (PREC == 2 && PIPE) ? 3 : 1;         // taps per step
+    static constexpr int RING = TPS == 3 ? 2 : NWBUF;
+    static constexpr int W_TAP = (PREC == 3 ? 2 : 1) * BN * 64;     // hi (+ lo) rows of one (tap, slice)
+    static constexpr int W_STAGE = TPS * W_TAP;
+    static constexpr int NI = W_TAP / (512 * 16);                   // DMA instructions per thread and tap
     static constexpr int EPI_BYTES = 128 * BN * 4;                  // 128 pixels per epilogue pass
-    static constexpr int MAIN_BYTES = S::HALO_BYTES + NWBUF * W_STAGE;
+    static constexpr int MAIN_BYTES = S::HALO_BYTES + RING * W_STAGE;
     static constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
 };
 
-template <int BN, int TWD>
+template <int BN, int TWD, int PREC, bool PIPE>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p) {
-    using T = HaloTile<BN, TWD>;
+    using T = HaloTile<BN, TWD, PREC, PIPE>;
+    constexpr int FMT = PREC == 2 ? FMT_F16 : FMT_BF16;
+    constexpr int TPS = T::TPS, RING = T::RING, W_TAP = T::W_TAP, SPS = 9 / TPS;   // SPS: steps per 32-channel slice
     using S = TileShape<TWD>;
     constexpr int TH = S::TH, TW = S::TW, HW = S::HW, RPB = S::RPB, HALO_PLANE = S::HALO_PLANE, HALO_BYTES = S::HALO_BYTES,
                   HALO_ITEMS = S::HALO_ITEMS, HALO_ITERS = S::HALO_ITERS;
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     const int ty = v % p.tiles_y, img = v / p.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW, n0 = tn * BN;
     const long Ktot = 9L * p.Cin;
-    const int nch = p.Cin >> 5, total = 9 * nch;
+    const int nch = p.Cin >> 5, total = SPS * nch;
     const float relu_floor = p.relu_in ? 0.f : -INFINITY;
 
     // ---- halo staging: item = (pixel q, channel group g of 4); every thread always issues HALO_ITERS loads (clamped
@@ -130,10 +140,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
             float xv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) xv[e] = inb[it] ? fmaxf(hreg[it][e], relu_floor) : 0.f;
-            hi[0] = pack_bf16x2(xv[0], xv[1]);
-            hi[1] = pack_bf16x2(xv[2], xv[3]);
-            lo[0] = pack_bf16x2(xv[0] - bf16_lo(hi[0]), xv[1] - bf16_hi(hi[0]));
-            lo[1] = pack_bf16x2(xv[2] - bf16_lo(hi[1]), xv[3] - bf16_hi(hi[1]));
+            hi[0] = pack_h2<FMT>(xv[0], xv[1]);       // fp16: saturating (an outlier beyond 65504 stays finite; lo takes the rest)
+            hi[1] = pack_h2<FMT>(xv[2], xv[3]);
+            lo[0] = pack_h2<FMT>(xv[0] - h2_lo<FMT>(hi[0]), xv[1] - h2_hi<FMT>(hi[0]));
+            lo[1] = pack_h2<FMT>(xv[2] - h2_lo<FMT>(hi[1]), xv[3] - h2_hi<FMT>(hi[1]));
             *reinterpret_cast<u32x2*>(halo + dst_off[it]) = hi;
             *reinterpret_cast<u32x2*>(halo + HALO_PLANE + dst_off[it]) = lo;
         }
@@ -151,13 +161,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
         gn = gn < p.Cout ? gn : p.Cout - 1;
         wsrc[k] = (plane ? p.w_lo : p.w_hi) + (long)gn * Ktot + ((sl ^ (n >> 2)) & 3) * 8;
     }
-    auto dma_w = [&](int s) {
-        const int c = s / 9, t = s - c * 9;
+    auto dma_tap = [&](int c, int t, char* dst) {    // weights of (slice c, tap t): NI pieces of 1 KiB per wave
         const int koff = t * p.Cin + c * 32;
-        char* dst = wring + (s % NWBUF) * W_STAGE;
 #pragma unroll
         for (int k = 0; k < NI; ++k)
             __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[k] + koff), (lptr_t*)(dst + (k * 8 + wave) * 1024), 16, 0, 0);
+    };
+    auto dma_w = [&](int s, int slot) {              // all taps of step s into ring slot `slot`
+        const int c = s / SPS, r = s - c * SPS;
+#pragma unroll
+        for (int u = 0; u < TPS; ++u) dma_tap(c, r * TPS + u, wring + slot * W_STAGE + u * W_TAP);
     };
 
     f32x16 acc[MI][2];
@@ -179,10 +192,75 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     // halo pixel of this lane's pixel of row block wm * MI for tap (0, 0): tile row (wm * MI) * RPB + frow / TW, column frow % TW
     const int q_base = ((wm * MI) * RPB + frow / TW) * HW + (frow % TW);
 
-    auto compute = [&](int s) {
-        const int t = s % 9;
-        const int ky = t / 3, kx = t - ky * 3;
-        const char* wb = wring + (s % NWBUF) * W_STAGE;
+    auto compute = [&](int s, int total_steps) {
+        const int r = s % SPS;
+        const char* wb = wring + (s % RING) * W_STAGE;
+        if constexpr (PIPE) {
+            // Software pipeline over the TPS * 2 * MI (tap, k-slice, row block) groups of the step: the fragments of group g + 2
+            // are requested TWO groups ahead of their MFMAs, so a group's LDS latency runs under the 4 ... 6 MFMAs of the group
+            // before it instead of in front of its own (the compiler's own order was read, wait, multiply per group).
+            // Three register sets for the A fragments (3 x 8 VGPRs instead of MI x 8), two B sets.
+            constexpr int GT = 2 * MI;                   // groups per tap
+            constexpr int G = TPS * GT;
+            constexpr int NB = PREC == 3 ? 4 : 2;        // B reads per (tap, k-slice)
+            const int q00 = q_base + (TPS == 3 ? r * HW : (r / 3) * HW + (r % 3));   // tap (ky, 0) resp. (ky, kx)
+            bf16x8 ah[3], al[3], bh[2][2], bl[2][2];
+            auto load_a = [&](int g, int set) {
+                const int u = g / GT, kc = (g % GT) / MI, i = g % MI;
+                const int q = q00 + u + i * RPB * HW;
+                const int off = q * 64 + ((((2 * kc + fhalf) ^ (q >> 2)) & 3) << 4);
+                ah[set] = *reinterpret_cast<const bf16x8*>(halo + off);
+                al[set] = *reinterpret_cast<const bf16x8*>(halo + HALO_PLANE + off);
+            };
+            auto load_b = [&](int kb) {                  // kb = (tap u, k-slice kc) block of MI groups
+                const int u = kb >> 1, kc = kb & 1;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bh[kb & 1][j] = *reinterpret_cast<const bf16x8*>(wb + u * W_TAP + boff[j][kc]);
+                    if (PREC == 3) bl[kb & 1][j] = *reinterpret_cast<const bf16x8*>(wb + u * W_TAP + BN * 64 + boff[j][kc]);
+                }
+            };
+            // the stage this step's DMA fills: step s + RING - 1 (clamped: past the end it re-fetches the last step's weights
+            // into the ring slot nobody reads any more -- a branch here would split the scheduling region)
+            const int sn = s + RING - 1 < total_steps ? s + RING - 1 : total_steps - 1;
+            const int cn = sn / SPS, rn = sn - cn * SPS;
+            char* dma_dst = wring + ((s + RING - 1) % RING) * W_STAGE;
+            load_b(0);
+            load_a(0, 0);
+            load_a(1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, NB + 4, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int kb = g / MI, i = g % MI, cur = g % 3;
+                if (g + 2 < G) {                        // two groups ahead: three register sets
+                    load_a(g + 2, (g + 2) % 3);
+                    if ((g + 2) % MI == 0) {
+                        load_b((g + 2) / MI);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NB, 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = mfma32h<FMT>(al[cur], bh[kb & 1][j], acc[i][j]);     // small terms first
+                    if (PREC == 3) acc[i][j] = mfma32h<FMT>(ah[cur], bl[kb & 1][j], acc[i][j]);
+                    acc[i][j] = mfma32h<FMT>(ah[cur], bh[kb & 1][j], acc[i][j]);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, PREC == 3 ? 6 : 4, 0);
+                if (g % GT == 0) {
+                    // One tap's weight DMA goes out HERE, behind the first group of each tap, not straight after the barrier:
+                    // an LDS-DMA piece costs its wave 60 ... 185 issue cycles (MI355X_MICROARCH.md), and right after the
+                    // barrier every wave of the workgroup pays them at the same moment with the matrix pipe empty (PMC: pipe
+                    // busy 53 % of the cycles, waves parked 33 %).
+                    const int u = g / GT;
+                    dma_tap(cn, rn * TPS + u, dma_dst + u * W_TAP);
+                    __builtin_amdgcn_sched_group_barrier(0x020, NI, 0);
+                }
+            }
+            return;
+        }
+        const int ky = r / 3, kx = r - ky * 3;
         const int q0 = q_base + ky * HW + kx;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
@@ -197,31 +275,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 bh[j] = *reinterpret_cast<const bf16x8*>(wb + boff[j][kc]);
-                bl[j] = *reinterpret_cast<const bf16x8*>(wb + BN * 64 + boff[j][kc]);
+                if (PREC == 3) bl[j] = *reinterpret_cast<const bf16x8*>(wb + BN * 64 + boff[j][kc]);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = mfma32(ah[i], bh[j], acc[i][j]);
-                    acc[i][j] = mfma32(ah[i], bl[j], acc[i][j]);
-                    acc[i][j] = mfma32(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = mfma32h<FMT>(ah[i], bh[j], acc[i][j]);
+                    if (PREC == 3) acc[i][j] = mfma32h<FMT>(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = mfma32h<FMT>(al[i], bh[j], acc[i][j]);
                 }
         }
     };
 
     // ---- prologue ---------------------------------------------------------------------------------------------------------
     halo_issue(0);
-    dma_w(0);
-    if (total > 1) dma_w(1);
+    dma_w(0, 0);
+    if (RING == 3) dma_w(total > 1 ? 1 : 0, 1);
     halo_write();                                   // (the compiler waits for the halo loads here)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    // ---- main loop: one barrier per step; step s waits for its own weights only (the DMA of step s + 1 stays in flight) ----
+    // ---- main loop: one barrier per step.  RING 3: step s waits for its own weights only (the DMA of step s + 1 stays in
+    //      flight); RING 2 (three taps per step): the stage filled during the previous step is the newest, wait for everything ---
 #pragma unroll 1
     for (int s = 0; s < total; ++s) {
-        const int c = s / 9, t = s - c * 9;
-        if (s + 1 < total) wait_vm<NI>();
+        const int c = s / SPS, t = s - c * SPS;
+        if (RING == 2) wait_vm<0>();
+        else if (PIPE || s + 1 < total) wait_vm<NI>();   // PIPE: every step issues one stage, so NI pieces are always the newest
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();               // W(s) landed in every wave; every wave finished step s - 1
         asm volatile("" ::: "memory");
@@ -233,9 +313,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (s + 2 < total) dma_w(s + 2);
+        if (!PIPE && s + 2 < total) dma_w(s + 2, (s + 2) % RING);
         if (t == 0 && c + 1 < nch) halo_issue(c + 1);
-        compute(s);
+        compute(s, total);
         __builtin_amdgcn_sched_barrier(0);          // ... and nothing of it below the next step's wait
     }
 
@@ -251,7 +331,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     {
         const int nb = n0 + (tid % C4) * 4;
-        if (p.bias && nb < p.Cout) bias4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
+        if (PREC == 2) {
+            if (nb < p.Cout) bias4 = *reinterpret_cast<const f32x4*>(p.corr + 4L * p.Cout + nb);   // class 4: interior
+        } else if (p.bias && nb < p.Cout) {
+            bias4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
+        }
     }
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
@@ -271,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
         for (int idx0 = tid; idx0 < 128 * C4; idx0 += EB * 512) {
             long pixs[EB];
             bool ok[EB];
-            f32x4 r1[EB], r2[EB];
+            f32x4 r1[EB], r2[EB], b4[EB];
 #pragma unroll
             for (int u = 0; u < EB; ++u) {
                 const int idx = idx0 + u * 512;
@@ -281,6 +365,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
                 const int n = n0 + c4 * 4;
                 ok[u] = idx < 128 * C4 && oy < p.H && ox < p.W && n < p.Cout;
                 pixs[u] = ok[u] ? ((long)img * p.H + oy) * p.W + ox : 0;
+                b4[u] = bias4;
+                if (PREC == 2 && ok[u]) {   // border pixels: the correction of their class (taps on the padding excluded)
+                    const int cls = (oy == 0 ? 0 : (oy == p.H - 1 ? 2 : 1)) * 3 + (ox == 0 ? 0 : (ox == p.W - 1 ? 2 : 1));
+                    if (cls != 4) b4[u] = *reinterpret_cast<const f32x4*>(p.corr + (long)cls * p.Cout + n);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { r1[u][e] = 0.f; r2[u][e] = 0.f; }
                 if (ok[u] && p.res) {
@@ -296,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
                 const int n = n0 + c4 * 4;
                 f32x4 vv = *reinterpret_cast<const f32x4*>(stile + row * BN + c4 * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) vv[e] += bias4[e];
+                for (int e = 0; e < 4; ++e) vv[e] += b4[u][e];
                 if (p.act == 1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) vv[e] = fmaxf(vv[e], 0.f);
@@ -318,13 +407,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     }
 }
 
-template <int BN, int TWD>
-int launch_halo(const HaloParams& p_in, hipStream_t st) {
-    using T = HaloTile<BN, TWD>;
+template <int BN, int TWD, int PREC, bool PIPE>
+int launch_halo_v(const HaloParams& p_in, hipStream_t st) {
+    using T = HaloTile<BN, TWD, PREC, PIPE>;
     constexpr int TW = TWD, TH = 256 / TWD;
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, TWD>,
+        const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, TWD, PREC, PIPE>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -334,28 +423,47 @@ int launch_halo(const HaloParams& p_in, hipStream_t st) {
     p.tiles_y = (p.H + TH - 1) / TH;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const long grid = (long)p.Nimg * p.tiles_y * p.tiles_x * p.tiles_n;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TWD>), dim3((unsigned)grid), dim3(512), T::SMEM, st, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TWD, PREC, PIPE>), dim3((unsigned)grid), dim3(512), T::SMEM, st, p);
     return 0;
+}
+
+// IGGT_CONV_HALO_PIPE=0: the un-pipelined fragment order (A/B runs)
+template <int BN, int TWD, int PREC>
+int launch_halo(const HaloParams& p, hipStream_t st) {
+    static int pipe = -1;
+    if (pipe < 0) {
+        const char* e = getenv("IGGT_CONV_HALO_PIPE");
+        pipe = (e && e[0] == '0') ? 0 : 1;
+    }
+    return pipe ? launch_halo_v<BN, TWD, PREC, true>(p, st) : launch_halo_v<BN, TWD, PREC, false>(p, st);
 }
 
 }  // namespace
 
-// Called by iggt_conv2d_nhwc_f32 (conv_igemm.hip).  Returns -100 when the problem is not one this kernel is built for.
-int iggt_launch_conv3x3_halo(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
-                             const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg, int H, int W,
-                             int Cin, int Cout, int relu_in, int relu_res, int act, hipStream_t st) {
+// Whether iggt_launch_conv3x3_halo takes the problem (the PREC = 2 caller has to know before it computes the corrections).
+bool iggt_conv3x3_halo_applies(const float* x, int ldx, const float* bias, const float* res, const float* res2, int ldr,
+                               const float* y, int ldy, int Nimg, int H, int W, int Cin, int Cout) {
     static int on = -1;
     if (on < 0) {
         const char* e = getenv("IGGT_CONV_HALO");
         on = (e && e[0] == '0') ? 0 : 1;
     }
-    if (!on || w_lo == nullptr || (Cin % 32) != 0 || (Cout % 128) != 0 || (ldx % 4) || (ldy % 4) || (res && (ldr % 4)))
-        return -100;
-    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)res2 | (uintptr_t)bias) % 16) return -100;
+    if (!on || (Cin % 32) != 0 || (Cout % 128) != 0 || (ldx % 4) || (ldy % 4) || (res && (ldr % 4))) return false;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)res2 | (uintptr_t)bias) % 16) return false;
     // small maps: the 8 x 32 tile wastes too much of its halo / MFMA rows (37 x 37 and below stay on the GEMM-shaped kernel)
-    if (W < 48 || H < 16 || (long)Nimg * H * W < 4096) return -100;
+    return !(W < 48 || H < 16 || (long)Nimg * H * W < 4096);
+}
+
+// Called by iggt_conv2d_nhwc_f32 (conv_igemm.hip).  Returns -100 when the problem is not one this kernel is built for.
+// prec 3: w_hi / w_lo bf16 planes, `bias`.  prec 2: w_hi = fp16 weights, w_lo unused, `corr` = [9][Cout] (bias included).
+int iggt_launch_conv3x3_halo(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
+                             const float* corr, const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg,
+                             int H, int W, int Cin, int Cout, int relu_in, int relu_res, int act, int prec, hipStream_t st) {
+    if (!iggt_conv3x3_halo_applies(x, ldx, bias, res, res2, ldr, y, ldy, Nimg, H, W, Cin, Cout)) return -100;
+    if (prec == 3 ? w_lo == nullptr : (prec != 2 || corr == nullptr || ((uintptr_t)corr % 16) != 0)) return -100;
     HaloParams p;
-    p.x = x; p.w_hi = (const bf16_t*)w_hi; p.w_lo = (const bf16_t*)w_lo; p.bias = bias; p.res = res; p.res2 = res2; p.y = y;
+    p.x = x; p.w_hi = (const bf16_t*)w_hi; p.w_lo = (const bf16_t*)w_lo; p.bias = bias; p.corr = corr; p.res = res; p.res2 = res2;
+    p.y = y;
     p.Nimg = Nimg; p.H = H; p.W = W; p.Cin = Cin; p.ldx = ldx; p.Cout = Cout; p.ldy = ldy; p.ldr = ldr;
     p.relu_in = relu_in; p.relu_res = relu_res; p.act = act;
     p.tiles_x = p.tiles_y = p.tiles_n = 0;
@@ -367,6 +475,10 @@ int iggt_launch_conv3x3_halo(const float* x, int ldx, const void* w_hi, const vo
     }
     const long wide = (long)((H + 7) / 8) * ((W + 31) / 32), square = (long)((H + 15) / 16) * ((W + 15) / 16);
     const bool sq = force ? force == 16 : square < wide;
-    if ((Cout % 256) == 0) return sq ? launch_halo<256, 16>(p, st) : launch_halo<256, 32>(p, st);
-    return sq ? launch_halo<128, 16>(p, st) : launch_halo<128, 32>(p, st);
+    if (prec == 2) {
+        if ((Cout % 256) == 0) return sq ? launch_halo<256, 16, 2>(p, st) : launch_halo<256, 32, 2>(p, st);
+        return sq ? launch_halo<128, 16, 2>(p, st) : launch_halo<128, 32, 2>(p, st);
+    }
+    if ((Cout % 256) == 0) return sq ? launch_halo<256, 16, 3>(p, st) : launch_halo<256, 32, 3>(p, st);
+    return sq ? launch_halo<128, 16, 3>(p, st) : launch_halo<128, 32, 3>(p, st);
 }

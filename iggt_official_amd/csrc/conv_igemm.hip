@@ -17,6 +17,10 @@
 // ~2^-16-relative products accumulated in fp32 -- fp32-grade results at 1/3 of the bf16 MFMA rate
 // (~5x the fp32-MFMA rate).  PREC=1 uses plain bf16 operands.  Activations are split on the fly in
 // the loader (fp32 -> hi/lo while staging to LDS); weights are pre-split once on the host side.
+// PREC=2: fp16 operands, activations hi + lo (exact to 2^-22), weights rounded ONCE to fp16 -- two
+// MFMAs per product; the mean response to the weight rounding is restored per border class by
+// conv_meancomp.hip (`corr`, added by the epilogue in place of the bias).  Head output error 1.7e-4 on
+// photographs with every layer at PREC=2 (profiles/r03_conv_precision.txt), against 1.2e-5 for PREC=3.
 //
 // Fused into the loader: ReLU on the input (ResidualConvUnit pre-activation).  Fused into the epilogue:
 // bias, ReLU / LeakyReLU(0.01) / exact GELU, residual add (optionally of the rectified residual -- the
@@ -40,6 +44,7 @@ struct ConvParams {
     const bf16_t* w_hi;    // [Cout][K] bf16, K = KH*KW*Cin (tap-major)
     const bf16_t* w_lo;    // PREC == 3 only
     const float* bias;     // [Cout] or null
+    const float* corr;     // PREC == 2 with padding: [9][Cout] bias + mean-input correction per border class, else null
     const float* res;      // residual, same indexing as y (ldr channels stride), or null
     const float* res2;     // second residual (never rectified), same layout as res, or null
     float* y;              // [Nimg][Hout][Wout][ldy]
@@ -75,7 +80,7 @@ struct ConvTile {
     static constexpr int THREADS = 64 * WAVES_M * WAVES_N;
     static constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     static constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64;
-    static constexpr int STAGE = (PREC == 3 ? 2 : 1) * (A_BYTES + W_BYTES);
+    static constexpr int STAGE = PREC == 3 ? 2 * (A_BYTES + W_BYTES) : PREC == 2 ? 2 * A_BYTES + W_BYTES : A_BYTES + W_BYTES;
     // the epilogue transposes the tile through the (then idle) stage ring, at most 128 KiB (= 128 rows of 256) a pass
     static constexpr int EPI_ROWS = (BM * BN * 4 > 131072) ? BM / 2 : BM;
     static constexpr int SMEM = (2 * STAGE > EPI_ROWS * BN * 4) ? 2 * STAGE : EPI_ROWS * BN * 4;
@@ -84,6 +89,7 @@ struct ConvTile {
 template <int PREC, int WM, int WN, int WAVES_M, int WAVES_N, bool SPLITK = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(const ConvParams pin) {
     using T = ConvTile<PREC, WM, WN, WAVES_M, WAVES_N>;
+    constexpr int FMT = PREC == 2 ? FMT_F16 : FMT_BF16;
     // SPLITK: this workgroup owns K chunks [kt_beg, kt_beg + kchunks) and writes its raw partial sums (no bias / activation
     // / residual, plain [M][Cout] layout) to its slice of the scratch buffer -- the epilogue code below runs unchanged on a
     // parameter block whose output side has been redirected.
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
         kt_beg = blockIdx.y * pin.kchunks;
         ploc.y = pin.part + (long)blockIdx.y * pin.M * pin.Cout;
         ploc.ldy = pin.Cout;
-        ploc.bias = nullptr; ploc.res = nullptr; ploc.res2 = nullptr;
+        ploc.bias = nullptr; ploc.corr = nullptr; ploc.res = nullptr; ploc.res2 = nullptr;
         ploc.act = 0; ploc.relu_res = 0;
     }
     const ConvParams& p = ploc;
@@ -196,23 +202,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
     auto swrite = [&](int buf, const Stage& R) {
         char* sAh = smem + buf * STAGE;
         char* sWh = sAh + A_BYTES;
-        char* sAl = sWh + W_BYTES;  // PREC == 3 only
-        char* sWl = sAl + A_BYTES;
+        char* sAl = sWh + W_BYTES;  // PREC >= 2 only
+        char* sWl = sAl + A_BYTES;  // PREC == 3 only
         u32x4 h[2], l[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float x0 = R.ra[2 * i + (e >> 1)][2 * (e & 1)], x1 = R.ra[2 * i + (e >> 1)][2 * (e & 1) + 1];
-                const uint32_t hp = pack_bf16x2(x0, x1);
+                const uint32_t hp = pack_h2<FMT>(x0, x1);
                 h[i][e] = hp;
-                if (PREC == 3) l[i][e] = pack_bf16x2(x0 - bf16_lo(hp), x1 - bf16_hi(hp));
+                if (PREC >= 2) l[i][e] = pack_h2<FMT>(x0 - h2_lo<FMT>(hp), x1 - h2_hi<FMT>(hp));
             }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int off = slot_swz(a_row, a_half * 2 + i);
             *reinterpret_cast<u32x4*>(sAh + off) = h[i];
-            if (PREC == 3) *reinterpret_cast<u32x4*>(sAl + off) = l[i];
+            if (PREC >= 2) *reinterpret_cast<u32x4*>(sAl + off) = l[i];
         }
 #pragma unroll
         for (int q = 0; q < W_PASSES; ++q) {
@@ -254,14 +260,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
                     const int off = slot_swz((wm * WM + i) * 32 + frow, 2 * kc + fhalf);
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(sAh + off);
                     bf16x8 al = ah;
-                    if (PREC == 3) al = *reinterpret_cast<const bf16x8*>(sAl + off);
+                    if (PREC >= 2) al = *reinterpret_cast<const bf16x8*>(sAl + off);
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
-                        if (PREC == 3) {  // small terms first
-                            acc[i][j] = mfma32(al, bh[j], acc[i][j]);
-                            acc[i][j] = mfma32(ah, bl[j], acc[i][j]);
-                        }
-                        acc[i][j] = mfma32(ah, bh[j], acc[i][j]);
+                        if (PREC >= 2) acc[i][j] = mfma32h<FMT>(al, bh[j], acc[i][j]);   // small terms first
+                        if (PREC == 3) acc[i][j] = mfma32h<FMT>(ah, bl[j], acc[i][j]);
+                        acc[i][j] = mfma32h<FMT>(ah, bh[j], acc[i][j]);
                     }
                 }
                 continue;
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
             for (int i = 0; i < WM; ++i) {
                 const int off = slot_swz((wm * WM + i) * 32 + frow, 2 * kc + fhalf);
                 ah[i] = *reinterpret_cast<const bf16x8*>(sAh + off);
-                if (PREC == 3) al[i] = *reinterpret_cast<const bf16x8*>(sAl + off);
+                if (PREC >= 2) al[i] = *reinterpret_cast<const bf16x8*>(sAl + off);
             }
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
@@ -283,11 +287,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
-                    if (PREC == 3) {  // small terms first
-                        acc[i][j] = mfma32(al[i], bh[j], acc[i][j]);
-                        acc[i][j] = mfma32(ah[i], bl[j], acc[i][j]);
-                    }
-                    acc[i][j] = mfma32(ah[i], bh[j], acc[i][j]);
+                    if (PREC >= 2) acc[i][j] = mfma32h<FMT>(al[i], bh[j], acc[i][j]);   // small terms first
+                    if (PREC == 3) acc[i][j] = mfma32h<FMT>(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = mfma32h<FMT>(ah[i], bh[j], acc[i][j]);
                 }
         }
     };
@@ -338,11 +340,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
     // the layers without a residual (same finding as gemm_bf16_t256.hip).
     static_assert(THREADS % C4 == 0, "a thread must keep its channel group over the epilogue passes");
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-        const int nb = n0 + (tid % C4) * 4;
+    {
+        const float* bsrc = p.corr ? p.corr + 4L * p.Cout : p.bias;   // class 4 = interior
+        if (bsrc) {
+            const int nb = n0 + (tid % C4) * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (nb + e < p.Cout) bias4[e] = p.bias[nb + e];
+            for (int e = 0; e < 4; ++e)
+                if (nb + e < p.Cout) bias4[e] = bsrc[nb + e];
+        }
     }
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
         long pixs[EB];
         int ns[EB], cos[EB];
         bool ok[EB];
-        f32x4 r1[EB], r2[EB];
+        f32x4 r1[EB], r2[EB], b4[EB];
 #pragma unroll
         for (int u = 0; u < EB; ++u) {
             const int idx = idx0 + u * THREADS;
@@ -378,6 +383,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
             const int img = (int)(mm / hw);
             const int rem = (int)(mm - (long)img * hw);
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            b4[u] = bias4;
+            if (PREC == 2 && p.corr && ok[u]) {   // border placements: the correction of their class (conv_meancomp.hip)
+                const int cls = (oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1)) * 3 + (ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1));
+                if (cls != 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.Cout) b4[u][e] = p.corr[(long)cls * p.Cout + n + e];
+                }
+            }
             int co = n, py = 0, px = 0;
             if (p.ps > 1) {
                 const int phase = n / p.cout_phys;
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
             f32x4 v = *reinterpret_cast<const f32x4*>(stile + row * BN + c4 * 4);
             const bool full = (n + 3 < p.Cout);  // Cout % 4 != 0 only for the padded 42-channel bottleneck
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+            for (int e = 0; e < 4; ++e) v[e] += b4[u][e];
             if (p.act == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -456,7 +470,15 @@ __global__ __launch_bounds__(256) void conv_splitk_finalize_kernel(const ConvPar
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += t[e];
     }
-    if (p.bias) {
+    if (p.corr) {   // PREC == 2: bias + mean-input correction of the placement's border class
+        const int hw = p.Ho * p.Wo;
+        const int rem = (int)(m % hw);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int cls = (oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1)) * 3 + (ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1));
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.corr + (long)cls * p.Cout + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += b[e];
+    } else if (p.bias) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += b[e];
@@ -481,11 +503,12 @@ __global__ __launch_bounds__(256) void conv_splitk_finalize_kernel(const ConvPar
 }
 
 // split-K launch of the 128 x 128 tile: ks slices of the K loop per output tile + the finalize pass
+template <int PREC>
 int launch_splitk(const ConvParams& p, int ks, int kchunks, float* part, hipStream_t st) {
-    using T = ConvTile<3, 2, 2, 2, 2>;
+    using T = ConvTile<PREC, 2, 2, 2, 2>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<3, 2, 2, 2, 2, true>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<PREC, 2, 2, 2, 2, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -494,7 +517,7 @@ int launch_splitk(const ConvParams& p, int ks, int kchunks, float* part, hipStre
     q.tiles_n = (p.Cout + T::BN - 1) / T::BN;
     q.ksplit = ks; q.kchunks = kchunks; q.part = part;
     const long tiles_m = (p.M + T::BM - 1) / T::BM;
-    hipLaunchKernelGGL((conv_igemm_kernel<3, 2, 2, 2, 2, true>), dim3((unsigned)(tiles_m * q.tiles_n), (unsigned)ks),
+    hipLaunchKernelGGL((conv_igemm_kernel<PREC, 2, 2, 2, 2, true>), dim3((unsigned)(tiles_m * q.tiles_n), (unsigned)ks),
                        dim3(T::THREADS), T::SMEM, st, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -525,8 +548,13 @@ int launch(const ConvParams& p, hipStream_t st) {
 
 // 3x3 / stride 1 / pad 1 fast path with a spatial halo tile (conv3x3_halo.hip); -100: not applicable
 int iggt_launch_conv3x3_halo(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
-                             const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg, int H, int W,
-                             int Cin, int Cout, int relu_in, int relu_res, int act, hipStream_t st);
+                             const float* corr, const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg,
+                             int H, int W, int Cin, int Cout, int relu_in, int relu_res, int act, int prec, hipStream_t st);
+// mean-input compensation of PREC = 2 (conv_meancomp.hip): channel means + the nine border-class correction vectors
+long iggt_conv_meancomp_ws_bytes(int Cin, int Cout);
+int iggt_launch_conv_meancomp(const float* x, int ldx, int Nimg, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH,
+                              int KW, int stride, int pad_y, int pad_x, int relu_in, const void* dw, const float* bias,
+                              void* ws, long ws_bytes, float** corr_out, int* uniform, hipStream_t st);
 
 extern "C" int iggt_conv2d_nhwc_f32_ws(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
                                        const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg, int Hi,
@@ -537,12 +565,13 @@ extern "C" int iggt_conv2d_nhwc_f32_ws(const float* x, int ldx, const void* w_hi
     if (Nimg <= 0 || Cin <= 0 || (Cin % BK) != 0 || Cout <= 0 || KH <= 0 || KW <= 0) return -1;
     if ((ldx % 4) != 0 || ldx < Cin) return -2;
     if ((ldy % 4) != 0 || (res && (ldr % 4) != 0) || (cout_phys % 4) != 0 && ps > 1) return -2;
-    if (prec != 1 && prec != 3) return -3;
-    if (prec == 3 && w_lo == nullptr) return -3;
+    if (prec != 1 && prec != 2 && prec != 3) return -3;
+    if (prec >= 2 && w_lo == nullptr) return -3;   // prec 3: bf16 lo plane; prec 2: bf16 residual W - fp16(W) (never an MFMA operand)
     if (res2 && !res) return -5;
     if (ps < 1 || cout_phys <= 0 || (ps > 1 && Cout != cout_phys * ps * ps)) return -4;
     ConvParams p;
-    p.x = x; p.w_hi = (const bf16_t*)w_hi; p.w_lo = (const bf16_t*)w_lo; p.bias = bias; p.res = res; p.res2 = res2; p.y = y;
+    p.x = x; p.w_hi = (const bf16_t*)w_hi; p.w_lo = (const bf16_t*)w_lo; p.bias = bias; p.corr = nullptr; p.res = res; p.res2 = res2;
+    p.y = y;
     p.Nimg = Nimg; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.ldx = ldx; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
     p.KH = KH; p.KW = KW; p.stride = stride; p.pad_y = pad_y; p.pad_x = pad_x;
     p.Hout = Hout; p.Wout = Wout; p.ldy = ldy; p.ldr = ldr;
@@ -552,10 +581,24 @@ extern "C" int iggt_conv2d_nhwc_f32_ws(const float* x, int ldx, const void* w_hi
     p.tiles_n = 0;
     p.ksplit = 1; p.kchunks = 0; p.part = nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (prec == 3 && KH == 3 && KW == 3 && stride == 1 && pad_y == 1 && pad_x == 1 && ps == 1 && osy == 1 && osx == 1 &&
+    if (prec == 2) {
+        // channel means of the input + correction vectors, into the head of the workspace (the split-K scratch follows)
+        float* corr = nullptr;
+        int uniform = 0;
+        const int mrc = iggt_launch_conv_meancomp(x, ldx, Nimg, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad_y, pad_x, relu_in,
+                                                  w_lo, bias, ws, ws_bytes, &corr, &uniform, st);
+        if (mrc == -100) return -6;   // no nine-class description of this geometry / no workspace: the caller asks for prec 3
+        if (mrc != 0) return mrc;
+        const long used = (iggt_conv_meancomp_ws_bytes(Cin, Cout) + 255) & ~255L;
+        ws = (char*)ws + used;
+        ws_bytes -= used;
+        if (uniform) p.bias = corr + 4L * Cout;   // 1 x 1 convolutions: one vector, the plain bias path
+        else p.corr = corr;
+    }
+    if (prec >= 2 && KH == 3 && KW == 3 && stride == 1 && pad_y == 1 && pad_x == 1 && ps == 1 && osy == 1 && osx == 1 &&
         ooy == 0 && oox == 0 && Ho == Hi && Wo == Wi && Hout == Hi && Wout == Wi && cout_phys == Cout) {
-        const int hrc = iggt_launch_conv3x3_halo(x, ldx, w_hi, w_lo, bias, res, res2, ldr, y, ldy, Nimg, Hi, Wi, Cin, Cout,
-                                                 relu_in, relu_res, act, st);
+        const int hrc = iggt_launch_conv3x3_halo(x, ldx, w_hi, w_lo, p.bias, p.corr, res, res2, ldr, y, ldy, Nimg, Hi, Wi, Cin,
+                                                 Cout, relu_in, relu_res, act, prec, st);
         if (hrc != -100) {
             if (hrc) return hrc;
             IGGT_CHECK_LAUNCH();
@@ -573,7 +616,7 @@ extern "C" int iggt_conv2d_nhwc_f32_ws(const float* x, int ldx, const void* w_hi
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             cus = prop.multiProcessorCount;
     }
-    const bool use_big = big && prec == 3 && (Cout % 256) == 0 && ((p.M + 255) / 256) * (Cout / 256) >= 2L * cus;
+    const bool use_big = big && prec >= 2 && (Cout % 256) == 0 && ((p.M + 255) / 256) * (Cout / 256) >= 2L * cus;
     int rc;
     // Few output pixels AND a long K (1024 channels x 9 taps = 288 chunks on a 19^2 / 37^2 map): every workgroup of the few
     // tiles walks the whole K alone (~1 us per chunk: 300 us whatever the map size).  Split K over grid.y so that the
@@ -584,7 +627,7 @@ extern "C" int iggt_conv2d_nhwc_f32_ws(const float* x, int ldx, const void* w_hi
         const char* e = getenv("IGGT_CONV_SPLITK");
         splitk = (e && e[0] == '0') ? 0 : 1;
     }
-    if (splitk && prec == 3 && !use_big && ws != nullptr && ((uintptr_t)ws % 16) == 0 && ps == 1 && osy == 1 && osx == 1 &&
+    if (splitk && prec >= 2 && !use_big && ws != nullptr && ((uintptr_t)ws % 16) == 0 && ps == 1 && osy == 1 && osx == 1 &&
         ooy == 0 && oox == 0 && Hout == Ho && Wout == Wo && cout_phys == Cout && Cout >= 128 && (Cout % 4) == 0 &&
         (ldy % 4) == 0 && (!res || (ldr % 4) == 0)) {
         const long tiles = ((p.M + 127) / 128) * ((Cout + 127) / 128);
@@ -597,7 +640,8 @@ extern "C" int iggt_conv2d_nhwc_f32_ws(const float* x, int ldx, const void* w_hi
             if (ks > 1) {
                 const int kchunks = (int)((KT + ks - 1) / ks);
                 ks = (KT + kchunks - 1) / kchunks;       // no empty slice
-                const int rc2 = launch_splitk(p, (int)ks, kchunks, (float*)ws, st);
+                const int rc2 = prec == 3 ? launch_splitk<3>(p, (int)ks, kchunks, (float*)ws, st)
+                                          : launch_splitk<2>(p, (int)ks, kchunks, (float*)ws, st);
                 if (rc2 != 0) return rc2;
                 IGGT_CHECK_LAUNCH();
                 return 0;
@@ -614,7 +658,7 @@ extern "C" int iggt_conv2d_nhwc_f32_ws(const float* x, int ldx, const void* w_hi
         narrow = (e && e[0] == '0') ? 0 : 1;
     }
     int bn = Cout > 64 ? 128 : Cout > 32 ? 64 : 32;
-    if (narrow && prec == 3 && !use_big) {
+    if (narrow && prec >= 2 && !use_big) {
         const long tiles_m = (p.M + 127) / 128;
         while (bn > 32 && tiles_m * ((Cout + bn - 1) / bn) * 4 < 3L * cus) bn >>= 1;   // fewer than 3/4 of the CUs busy
     }
@@ -623,6 +667,11 @@ extern "C" int iggt_conv2d_nhwc_f32_ws(const float* x, int ldx, const void* w_hi
         else if (bn == 128) rc = launch<3, 2, 2, 2, 2>(p, st);
         else if (bn == 64) rc = launch<3, 1, 2, 4, 1>(p, st);
         else rc = launch<3, 1, 1, 4, 1>(p, st);
+    } else if (prec == 2) {
+        if (use_big) rc = launch<2, 4, 2, 2, 4>(p, st);
+        else if (bn == 128) rc = launch<2, 2, 2, 2, 2>(p, st);
+        else if (bn == 64) rc = launch<2, 1, 2, 4, 1>(p, st);
+        else rc = launch<2, 1, 1, 4, 1>(p, st);
     } else {
         if (Cout > 64) rc = launch<1, 2, 2, 2, 2>(p, st);
         else if (Cout > 32) rc = launch<1, 1, 2, 4, 1>(p, st);

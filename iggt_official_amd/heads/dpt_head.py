@@ -44,6 +44,11 @@ def custom_interpolate(x, size=None, scale_factor=None, mode="bilinear", align_c
     return co.resize(nhwc, tuple(int(v) for v in size)).permute(0, 3, 1, 2)
 
 
+# FeatureFusionBlock: 1 x 1 out_conv before the upsampling instead of after it (exact identity, see forward_nhwc).
+# IGGT_OUT_CONV_FIRST=0 restores the reference's order.
+OUT_CONV_FIRST = os.environ.get("IGGT_OUT_CONV_FIRST", "1") != "0"
+
+
 class ResidualConvUnit(nn.Module):
     """conv2(relu(conv1(relu(x)))) + relu(x): the skip adds the *rectified* input because the
     reference's activation is nn.ReLU(inplace=True) (dpt_head.py:327,401,411)."""
@@ -57,12 +62,13 @@ class ResidualConvUnit(nn.Module):
         self.norm2 = None
         self._pk = co.PackCache()
 
-    def forward_nhwc(self, x, extra=None):
-        """x NHWC -> conv2(relu(conv1(relu x))) + relu(x) (+ extra)."""
+    def forward_nhwc(self, x, extra=None, prec=None):
+        """x NHWC -> conv2(relu(conv1(relu x))) + relu(x) (+ extra).  prec: operand precision of the two convolutions
+        (None = convops.PREC; the DPT depth / point heads pass convops.DPT_PREC)."""
         p1 = self._pk.get(1, (self.conv1.weight, self.conv1.bias), lambda: co.pack_conv2d(self.conv1))
         p2 = self._pk.get(2, (self.conv2.weight, self.conv2.bias), lambda: co.pack_conv2d(self.conv2))
-        t = co.run(p1, x, relu_in=True, act=1)
-        return co.run(p2, t, res=x, relu_res=True, res2=extra)
+        t = co.run(p1, x, relu_in=True, act=1, prec=prec)
+        return co.run(p2, t, res=x, relu_res=True, res2=extra, prec=prec)
 
 
 class FeatureFusionBlock(nn.Module):
@@ -79,17 +85,23 @@ class FeatureFusionBlock(nn.Module):
         self.size = size
         self._pk = co.PackCache()
 
-    def forward_nhwc(self, x0, x1=None, size=None):
+    def forward_nhwc(self, x0, x1=None, size=None, prec=None):
         """reference FeatureFusionBlock.forward (dpt_head.py:455-481) on NHWC tensors."""
         y = x0
         if self.has_residual:
-            y = self.resConfUnit1.forward_nhwc(x1, extra=x0)      # x0 + rcu1(x1), the add is fused
-        y = self.resConfUnit2.forward_nhwc(y)
+            y = self.resConfUnit1.forward_nhwc(x1, extra=x0, prec=prec)      # x0 + rcu1(x1), the add is fused
+        y = self.resConfUnit2.forward_nhwc(y, prec=prec)
         if size is None:
             size = self.size if self.size is not None else (2 * y.shape[1], 2 * y.shape[2])
-        y = co.resize(y, tuple(size))
         pc = self._pk.get(0, (self.out_conv.weight, self.out_conv.bias), lambda: co.pack_conv2d(self.out_conv))
-        return co.run(pc, y)
+        if OUT_CONV_FIRST and size[0] * size[1] > y.shape[1] * y.shape[2]:
+            # The reference interpolates, then applies the 1 x 1 out_conv (dpt_head.py:471-479).  Both are linear maps that act
+            # on different axes (pixels / channels) and the interpolation weights of a pixel sum to 1 (bias), so they commute
+            # exactly; run the convolution on the SMALL map -- a quarter of the pixels (refinenet1: 2.1 -> 0.55 ms per head at 32
+            # views).  Only the fp32 rounding order differs (~1e-7, tests/test_heads_gpu.py compares both orders).
+            return co.resize(co.run(pc, y, prec=prec), tuple(size))
+        y = co.resize(y, tuple(size))
+        return co.run(pc, y, prec=prec)
 
 
 def _make_fusion_block(features, size=None, has_residual=True, groups=1):
@@ -191,6 +203,11 @@ class DPTHead(nn.Module):
     def _conv(self, key, conv):
         return self._pk.get(key, (conv.weight, conv.bias), lambda: co.pack_conv2d(conv))
 
+    def _prec(self):
+        """Operand precision of this head's convolutions: convops.DPT_PREC for the depth / point heads (measured per layer,
+        profiles/r03_conv_precision.txt); the tracker's feature extractor stays at convops.PREC."""
+        return None if self.for_tracker else co.DPT_PREC
+
     def forward(self, aggregated_tokens_list, images, patch_start_idx, frames_chunk_size=FRAMES_CHUNK):
         """Returns (preds [1,S,H,W,c], conf [1,S,H,W][, (out2,out3,out4) NHWC fusion features])."""
         B, S, _, H, W = images.shape
@@ -227,9 +244,9 @@ class DPTHead(nn.Module):
             rl = self.resize_layers[i]
             if isinstance(rl, nn.ConvTranspose2d):
                 pc = self._pk.get(("rl", i), (rl.weight, rl.bias), lambda rl=rl: co.pack_convT_kernel_eq_stride(rl))
-                x = co.run(pc, x)
+                x = co.run(pc, x, prec=self._prec())
             elif isinstance(rl, nn.Conv2d):
-                x = co.run(self._conv(("rl", i), rl), x)
+                x = co.run(self._conv(("rl", i), rl), x, prec=self._prec())
             maps.append(x)
         return maps
 
@@ -264,7 +281,7 @@ class DPTHead(nn.Module):
             out = co.resize(out, size)
         if self.for_tracker:
             return out.permute(0, 3, 1, 2)[None]
-        out = co.run(self._conv("oc2_0", c2[0]), out, act=1)                 # conv3x3 128->32 + ReLU
+        out = co.run(self._conv("oc2_0", c2[0]), out, act=1, prec=self._prec())   # conv3x3 128->32 + ReLU
         if (c2[2].in_channels == 32 and 2 <= c2[2].out_channels <= 8 and self.activation in _C.HEAD_ACT
                 and self.conf_activation in _C.CONF_ACT):
             # 1x1 conv 32 -> 4|2 + activate_head in one HBM pass (csrc/elementwise.hip head_tail_kernel)
@@ -282,10 +299,10 @@ class DPTHead(nn.Module):
 
     def scratch_forward(self, features: List[torch.Tensor]):
         """reference dpt_head.py:286-316 on NHWC maps -> (output_conv1 map, (out2, out3, out4))."""
-        sc = self.scratch
-        r = [co.run(self._conv(("rn", i), getattr(sc, f"layer{i + 1}_rn")), features[i]) for i in range(4)]
-        out4 = sc.refinenet4.forward_nhwc(r[3], size=r[2].shape[1:3])
-        out3 = sc.refinenet3.forward_nhwc(out4, r[2], size=r[1].shape[1:3])
-        out2 = sc.refinenet2.forward_nhwc(out3, r[1], size=r[0].shape[1:3])
-        out1 = sc.refinenet1.forward_nhwc(out2, r[0])
-        return co.run(self._conv("oc1", sc.output_conv1), out1), (out2, out3, out4)
+        sc, prec = self.scratch, self._prec()
+        r = [co.run(self._conv(("rn", i), getattr(sc, f"layer{i + 1}_rn")), features[i], prec=prec) for i in range(4)]
+        out4 = sc.refinenet4.forward_nhwc(r[3], size=r[2].shape[1:3], prec=prec)
+        out3 = sc.refinenet3.forward_nhwc(out4, r[2], size=r[1].shape[1:3], prec=prec)
+        out2 = sc.refinenet2.forward_nhwc(out3, r[1], size=r[0].shape[1:3], prec=prec)
+        out1 = sc.refinenet1.forward_nhwc(out2, r[0], prec=prec)
+        return co.run(self._conv("oc1", sc.output_conv1), out1, prec=prec), (out2, out3, out4)

@@ -35,6 +35,7 @@ import os
 from .. import _C, precision
 from ..dist import ViewShard
 from ..graphs import GraphCache
+from ..heads import convops
 from ..heads.adaptor import SamProjector
 from ..heads.camera_head import CameraHead
 from ..heads.dpt_head import DPTHead
@@ -83,6 +84,7 @@ class _Base(nn.Module, PyTorchModelHubMixin):
         # everything that selects WHICH kernels / collectives get captured is part of the key
         key = (tuple(images.shape), precision.operand_name(), precision.static_softmax(),
                precision.mean_compensation_sites(), precision.gather_overlap(), precision.debug_saturation(), precision.static_guard(),
+               convops.PREC, convops.DPT_PREC,
                None if shard is None else (shard.rank, shard.world, shard.kv_groups, shard.force))
 
         def fwd(static_in, ctl):

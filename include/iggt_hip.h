@@ -222,6 +222,11 @@ int iggt_write_special_tokens(float* dst, long view_stride, long ldd, const floa
  * (oy*osy + ooy + py, ox*osx + oox + px) in an Hout x Wout map, where (py, px) = phase of n / cout_phys when
  * ps > 1 (pixel shuffle: ConvTranspose2d with kernel == stride).  relu_in: ReLU on loaded inputs; res: residual
  * added after the activation (relu_res: add max(res,0)); res2: optional second residual (plain add); act: 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 GELU(erf).
+ * prec 2 (needs the _ws entry point): w_hi = fp16(W) [Cout][KH*KW*Cin], w_lo = bf16(W - fp16(W)); the MFMAs multiply
+ * fp16 hi + fp16 lo activations (exact to 2^-22) by w_hi -- two passes instead of three -- and the epilogue adds, in place of
+ * the bias, bias + mean_input * w_lo summed over the taps that fall inside the image for the placement's border class
+ * (first / middle / last row x column: nine vectors, computed per call by two small kernels from a strided sample of the
+ * input; csrc/conv_meancomp.hip).  Returns -6 for a geometry without such a description (pad > stride) or without workspace.
  * Replaces the nn.Conv2d / nn.ConvTranspose2d of iggt/heads/dpt_head.py:72-128,345-411,441-479,
  * iggt/heads/adaptor.py:9-35,152-175 and iggt/heads/window_sa.py:40-47,383-391. */
 int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
@@ -232,7 +237,8 @@ int iggt_conv2d_nhwc_f32(const float* x, int ldx, const void* w_hi, const void* 
                          void* stream);
 /* The same with a scratch buffer (16-byte aligned, used by one call at a time on a stream) that lets plain convolutions with
  * few output tiles and a long K (1024 channels x 9 taps on the 19^2 / 37^2 maps of 3-4 views) split the K loop over
- * several workgroups per tile; the partial tiles are added in a fixed order by a finalize pass.  ws == NULL: as above. */
+ * several workgroups per tile; the partial tiles are added in a fixed order by a finalize pass.  ws == NULL: as above.
+ * prec 2 keeps its channel sums and correction vectors in the first (64 Cin + 9 Cout) * 4 + 256 bytes of ws. */
 int iggt_conv2d_nhwc_f32_ws(const float* x, int ldx, const void* w_hi, const void* w_lo, const float* bias,
                          const float* res, const float* res2, int ldr, float* y, int ldy, int Nimg, int Hi, int Wi,
                          int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_y,

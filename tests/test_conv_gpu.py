@@ -263,3 +263,169 @@ def test_dpt_tail_fused_vs_separate_kernels(hw_in, size, cout, act, pos):
     xyz = lin[..., :-1]
     ref = {"inv_log": torch.sign(xyz) * torch.expm1(xyz.abs()), "exp": xyz.exp(), "linear": xyz}[act]
     assert _err(pts, ref)[0] < 5e-5 and _err(conf, 1 + lin[..., -1].exp())[0] < 5e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# prec = 2: fp16 activations hi + lo x weights rounded once to fp16 + mean-input compensation per border class
+# (csrc/conv_meancomp.hip).  Three checks per geometry, the first two EXACT (fp32-grade) by construction:
+#   (a) weights that are fp16 numbers: nothing is rounded, the correction is the bias -> the MFMA path alone
+#   (b) generic weights, an input that is constant per channel: x == mu everywhere, so the correction restores the weight
+#       rounding completely -- including the first / last rows and columns, where the padded taps drop out (all nine classes)
+#   (c) generic weights, rectified noise with a large mean: the statistical gate (weight rounding 2^-12, mean removed)
+@pytest.fixture
+def force_prec2():
+    """convops.run demotes small prec-2 requests to prec 3 (PREC2_MIN_FLOPS); the kernel tests want the prec-2 kernels."""
+    from iggt_official_amd.heads import convops as co
+
+    old, co.PREC2_MIN_FLOPS = co.PREC2_MIN_FLOPS, 0.0
+    yield
+    co.PREC2_MIN_FLOPS = old
+
+
+_P2 = [  # cin, cout, k, stride, pad, n, (h, w)                       kernel the launcher picks
+    (256, 256, 3, 1, 1, 2, (74, 74)),      # halo 256 x (16 x 16 tile)
+    (256, 128, 3, 1, 1, 1, (70, 100)),     # halo 128 x (8 x 32)
+    (64, 128, 3, 1, 1, 3, (16, 50)),       # halo, two 32-channel slices
+    (256, 256, 3, 1, 1, 3, (37, 41)),      # GEMM-shaped 128 x 128 (map below the halo threshold)
+    (1024, 256, 3, 1, 1, 4, (19, 19)),     # split K
+    (1024, 1024, 3, 2, 1, 4, (37, 37)),    # stride 2 (odd map: the last row sees the padding), split K
+    (256, 256, 3, 2, 1, 2, (24, 36)),      # stride 2, even map: the last row / column sees no padding
+    (256, 256, 1, 1, 0, 3, (30, 50)),      # 1 x 1: one correction vector through the bias path
+    (128, 32, 3, 1, 1, 2, (56, 70)),       # narrow column tile
+    (128, 64, 3, 1, 1, 1, (16, 24)),
+    (256, 256, 3, 1, 1, 6, (150, 151)),    # halo, ragged tiles both ways, sampled mean (step > 1)
+    (64, 512, 1, 1, 0, 6, (150, 151)),     # 256 x 256 GEMM tile
+    (128, 256, 3, 2, 1, 6, (150, 151)),    # 256 x 256 GEMM tile with border classes
+]
+
+
+def _p2_conv(cin, cout, k, stride, pad, seed, fp16_weights):
+    conv = nn.Conv2d(cin, cout, k, stride, pad).cuda()
+    with torch.no_grad():
+        w = _mk(conv.weight.shape, seed, (cin * k * k) ** -0.5)
+        conv.weight.copy_(w.half().float() if fp16_weights else w)
+        conv.bias.copy_(_mk(conv.bias.shape, seed + 1, 0.1))
+    return conv
+
+
+def _ref64(conv, x_nhwc, relu_in=False):
+    xd = x_nhwc.permute(0, 3, 1, 2).double()
+    return F.conv2d(F.relu(xd) if relu_in else xd, conv.weight.double(), conv.bias.double(), conv.stride, conv.padding)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,n,hw", _P2)
+def test_conv_prec2_exact_cases_and_statistical_gate(cin, cout, k, stride, pad, n, hw, force_prec2):
+    from iggt_official_amd.heads import convops as co
+
+    big = n * hw[0] * hw[1] > 50000                      # fp64 reference on a crop of the first and last image only
+    def check(conv, x, gate_max, gate_l2=None, relu_in=False, tag=""):
+        y = co.run(co.pack_conv2d(conv), x, prec=2, relu_in=relu_in)
+        assert torch.isfinite(y).all()
+        worst = (0.0, 0.0)
+        for img in ((0, n - 1) if big else range(n)):
+            ref = _ref64(conv, x[img:img + 1], relu_in)
+            got = y[img:img + 1].permute(0, 3, 1, 2)
+            worst = max(worst, _err(got, ref))
+        report(f"conv_p2_{cin}_{cout}_k{k}s{stride}_{hw[0]}x{hw[1]}{tag}", dict(max=worst[0], l2=worst[1]))
+        assert worst[0] < gate_max and (gate_l2 is None or worst[1] < gate_l2), (tag, worst)
+
+    # (a) fp16-representable weights
+    check(_p2_conv(cin, cout, k, stride, pad, 51, True), _mk((n, hw[0], hw[1], cin), 53), 2e-5, tag="_a")
+    # (b) per-channel constant input (positive and negative constants; no ReLU on load)
+    const = _mk((1, 1, 1, cin), 54) + 0.5
+    check(_p2_conv(cin, cout, k, stride, pad, 55, False), const.expand(n, hw[0], hw[1], cin).contiguous(), 2e-5, tag="_b")
+    # (c) rectified noise on load, mean ~0.9 sigma: weight rounding minus its mean response
+    check(_p2_conv(cin, cout, k, stride, pad, 57, False), _mk((n, hw[0], hw[1], cin), 59) + 0.5, 1.5e-3, 3e-4, relu_in=True,
+          tag="_c")
+
+
+def test_conv_prec2_fused_epilogue_and_residuals(force_prec2):
+    """prec 2 through every epilogue feature (residuals, rectified residual, activations, in-place residual) on the halo kernel
+    and on the GEMM-shaped kernel, with fp16-representable weights so that the comparison is fp32-grade."""
+    from iggt_official_amd.heads import convops as co
+
+    for hw in ((40, 64), (20, 28)):                      # halo kernel / GEMM-shaped kernel
+        conv = _p2_conv(256, 256, 3, 1, 1, 61, True)
+        pc = co.pack_conv2d(conv)
+        x, r1, r2 = _mk((2, hw[0], hw[1], 256), 63), _mk((2, hw[0], hw[1], 256), 64), _mk((2, hw[0], hw[1], 256), 65)
+        base = _ref64(conv, x, relu_in=True)
+        y = co.run(pc, x, relu_in=True, res=r1, relu_res=True, res2=r2, prec=2)
+        want = base + F.relu(r1.permute(0, 3, 1, 2).double()) + r2.permute(0, 3, 1, 2).double()
+        assert _err(y.permute(0, 3, 1, 2), want)[0] < 2e-5
+        for act, fn in [(1, F.relu), (2, lambda t: F.leaky_relu(t, 0.01)), (3, F.gelu)]:
+            y = co.run(pc, x, relu_in=True, act=act, prec=2)
+            assert _err(y.permute(0, 3, 1, 2), fn(base))[0] < 2e-5, act
+        out = r1.clone()
+        co.run(pc, x, relu_in=True, res=out, out=out, prec=2)
+        assert _err(out.permute(0, 3, 1, 2), base + r1.permute(0, 3, 1, 2).double())[0] < 2e-5
+        # the same pack serves prec 3 (its own planes, built from the fp32 weights) and agrees
+        y3 = co.run(pc, x, relu_in=True, prec=3)
+        assert _err(y3.permute(0, 3, 1, 2), base)[0] < 2e-5
+
+
+@pytest.mark.parametrize("s", [2, 4])
+def test_conv_prec2_transpose_kernel_eq_stride(s, force_prec2):
+    from iggt_official_amd.heads import convops as co
+
+    ct = nn.ConvTranspose2d(256, 256, s, s, 0).cuda()
+    x = (_mk((2, 9, 13, 256), 12) + 0.5).relu()
+    y = co.run(co.pack_convT_kernel_eq_stride(ct), x, prec=2)
+    ref = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), ct.weight.double(), ct.bias.double(), s, 0)
+    mx, l2 = _err(y.permute(0, 3, 1, 2), ref)
+    assert mx < 1.5e-3 and l2 < 3e-4, (mx, l2)
+    xc = (_mk((1, 1, 1, 256), 13) + 0.5).expand(2, 9, 13, 256).contiguous()          # constant per channel: exact
+    y = co.run(co.pack_convT_kernel_eq_stride(ct), xc, prec=2)
+    ref = F.conv_transpose2d(xc.permute(0, 3, 1, 2).double(), ct.weight.double(), ct.bias.double(), s, 0)
+    assert _err(y.permute(0, 3, 1, 2), ref)[0] < 2e-5
+
+
+def test_conv_prec2_transpose_k4s2p1_border_classes(force_prec2):
+    """The four 2 x 2 parity convolutions of ConvTranspose2d(k4, s2, p1) pad one side only: per-axis border masks differ between
+    the first and the last placement.  Constant-per-channel input -> exact."""
+    from iggt_official_amd.heads import convops as co
+
+    ct = nn.ConvTranspose2d(256, 256, 4, 2, 1).cuda()
+    xc = (_mk((1, 1, 1, 256), 14) + 0.5).expand(2, 7, 10, 256).contiguous()
+    y = co.run_convT_k4s2p1(co.pack_convT_k4s2p1(ct), xc, prec=2)
+    ref = F.conv_transpose2d(xc.permute(0, 3, 1, 2).double(), ct.weight.double(), ct.bias.double(), 2, 1)
+    assert _err(y.permute(0, 3, 1, 2), ref)[0] < 2e-5
+
+
+def test_conv_prec2_small_problems_run_at_prec3():
+    """Below PREC2_MIN_FLOPS a prec-2 request runs the split-bf16 kernels: fp32-grade on generic weights."""
+    from iggt_official_amd.heads import convops as co
+
+    conv = _p2_conv(256, 256, 3, 1, 1, 71, False)
+    x = _mk((2, 20, 28, 256), 73)
+    y = co.run(co.pack_conv2d(conv), x, prec=2)
+    assert _err(y.permute(0, 3, 1, 2), _ref64(conv, x))[0] < 2e-5
+
+
+def test_fusion_block_out_conv_before_resize_is_the_same_map():
+    """FeatureFusionBlock: the 1 x 1 out_conv applied before the bilinear upsampling (dpt_head.OUT_CONV_FIRST) against the
+    reference's order (interpolate, then out_conv: dpt_head.py:471-479) and against fp64 PyTorch."""
+    from iggt_official_amd.heads import dpt_head as dh
+
+    blk = dh._make_fusion_block(256).cuda()
+    with torch.no_grad():
+        for i, prm in enumerate(blk.parameters()):
+            prm.copy_(_mk(prm.shape, 80 + i, 0.02 if prm.dim() == 4 else 0.1))
+    x0, x1 = _mk((2, 20, 28, 256), 90), _mk((2, 20, 28, 256), 91)
+    old = dh.OUT_CONV_FIRST
+    try:
+        dh.OUT_CONV_FIRST = True
+        first = blk.forward_nhwc(x0, x1, size=(37, 53))
+        dh.OUT_CONV_FIRST = False
+        after = blk.forward_nhwc(x0, x1, size=(37, 53))
+    finally:
+        dh.OUT_CONV_FIRST = old
+    assert first.shape == after.shape == (2, 37, 53, 256)
+    assert _err(first, after)[0] < 2e-5             # both orders run split-bf16 products (2^-16 each)
+    xd0, xd1 = x0.permute(0, 3, 1, 2).double(), x1.permute(0, 3, 1, 2).double()
+    b = blk.double()
+    def rcu(m, t):
+        r = F.relu(t)
+        return m.conv2(F.relu(m.conv1(r))) + r
+    y = rcu(b.resConfUnit2, xd0 + rcu(b.resConfUnit1, xd1))
+    ref = b.out_conv(F.interpolate(y, size=(37, 53), mode="bilinear", align_corners=True))
+    assert _err(first.permute(0, 3, 1, 2), ref)[0] < 2e-5
