@@ -145,3 +145,37 @@ def test_demo_chain_bf16_operands(case):
     report(f"real/{case}/bf16", {k: dict(max=v[0], l2=v[1], l2_centered=v[2]) for k, v in res.items()})
     for k, v in res.items():
         assert v[1] < 1e-2 and v[0] < 3e-2, (k, v)
+
+
+@pytest.mark.parametrize("case", ["real_demo7_s4_crop518_stress", "real_demo7_s4_336x504_stress"])
+def test_head_convolutions_two_passes_vs_three_on_photographs(case):
+    """The DPT heads at convops.DPT_PREC = 2 (fp16 hi + lo activations x fp16 weights + mean-input compensation: two MFMA
+    passes, what ships) against the same forward at 3 (split-bf16, fp32-grade): the head-only difference the cheaper operand
+    format costs -- VERDICT r2 item 5 allows 5e-4 l2 / 1e-3 max per head output (probes/conv_precision.py predicted 1.7e-4) --
+    and both against the reference fixture."""
+    from iggt_official_amd import precision
+    from iggt_official_amd.heads import convops as co
+
+    g = load_golden(case)
+    m = g["meta"]
+    ss = m["spatial_stride"]
+    model = build_gpu_model(m["mode"], m["weight_seed"])
+    images = _load(m)
+    precision.set_operand_dtype("f16")
+    old = co.DPT_PREC
+    try:
+        co.DPT_PREC = 3
+        p3 = {k: v.clone() for k, v in model(images).items() if torch.is_tensor(v)}
+        co.DPT_PREC = 2
+        p2 = {k: v.clone() for k, v in model(images).items() if torch.is_tensor(v)}
+    finally:
+        co.DPT_PREC = old
+    out = {}
+    for k in ("depth", "depth_conf", "world_points", "world_points_conf"):
+        d = errors(p2[k], p3[k])
+        out[k] = dict(head_only_max=d[0], head_only_l2=d[1],
+                      prec3_vs_reference_l2=errors(p3[k][:, :, ::ss, ::ss], g[k])[1],
+                      prec2_vs_reference_l2=errors(p2[k][:, :, ::ss, ::ss], g[k])[1])
+        assert d[1] < 5e-4 and d[0] < 1e-3, (k, d)
+    assert torch.equal(p2["pose_enc"], p3["pose_enc"])       # the camera head has no convolution
+    report(f"real/{case}/head_conv_prec2_vs_prec3", out)
