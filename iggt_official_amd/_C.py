@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -102,6 +102,9 @@ _SIGNATURES = {
     "iggt_project3_f32": [_c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "iggt_stretch3_f32": [_c_void_p, _c_long, _c_void_p, _c_void_p],
     "iggt_nn1_label_f32": [_c_void_p, _c_long, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "iggt_nn1_search_split_f32": [_c_void_p, _c_long, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "iggt_nn1_label_tiled_f32": [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_int,
+                                 _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "iggt_count_saturated_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "iggt_layernorm_rows_f32": [_c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
                                 _c_int, _c_float, _c_void_p],
@@ -116,7 +119,7 @@ _SIGNATURES = {
                               _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_float, _c_void_p],
     "iggt_track_update_f32": [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_int, _c_int, _c_float, _c_void_p],
     "iggt_hdbscan_core_dist_f32": [_c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
-    "iggt_hdbscan_nearest_foreign_f32": [_c_void_p] * 8 + [_c_long, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "iggt_hdbscan_nearest_foreign_f32": [_c_void_p] * 8 + [_c_long, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
     "iggt_hdbscan_labels_from_mst": [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, ctypes.c_double, _c_int, _c_void_p],
     "iggt_write_special_tokens": [_c_void_p, _c_long, _c_long, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_void_p],
@@ -771,10 +774,45 @@ def nn1_label(query, ref, ref_labels):
     _dev(query, ref, ref_labels)
     _f32_all(query, ref)
     assert ref_labels.dtype == torch.int32 and ref_labels.is_contiguous() and query.shape[1] == ref.shape[1]
-    out = torch.empty(query.shape[0], dtype=torch.int32, device=query.device)
-    rc = load().iggt_nn1_label_f32(query.data_ptr(), query.shape[0], ref.data_ptr(), ref.shape[0], ref.shape[1],
-                                   ref_labels.data_ptr(), out.data_ptr(), _stream())
+    Mq, Mr = query.shape[0], ref.shape[0]
+    qtiles, rtiles = (Mq + 255) // 256, (Mr + 255) // 256
+    nsplit = min(rtiles, max(1, 2048 // qtiles))      # enough workgroups to fill the chip when the queries alone do not
+    if nsplit > 1:
+        d2 = torch.empty(nsplit, Mq, dtype=torch.float32, device=query.device)
+        bi = torch.empty(nsplit, Mq, dtype=torch.int32, device=query.device)
+        rc = load().iggt_nn1_search_split_f32(query.data_ptr(), Mq, ref.data_ptr(), Mr, ref.shape[1], nsplit, d2.data_ptr(),
+                                              bi.data_ptr(), _stream())
+        _check(rc, "iggt_nn1_search_split_f32")
+        # planes cover increasing index ranges: the first plane holding the smallest distance holds the first minimum
+        # (strict < inside a plane keeps the first one there; a NaN distance never wins, like in the one-pass kernel)
+        dmin = d2.amin(0, keepdim=True)
+        hit = (d2 == dmin) & (bi >= 0)
+        first = torch.where(hit.any(0), hit.int().argmax(0), torch.zeros((), dtype=torch.int64, device=query.device))
+        idx = bi.gather(0, first[None])[0].long()
+        return torch.where(idx >= 0, ref_labels[idx.clamp(min=0)], torch.full((), -1, dtype=torch.int32, device=query.device))
+    out = torch.empty(Mq, dtype=torch.int32, device=query.device)
+    rc = load().iggt_nn1_label_f32(query.data_ptr(), Mq, ref.data_ptr(), Mr, ref.shape[1], ref_labels.data_ptr(), out.data_ptr(),
+                                   _stream())
     _check(rc, "iggt_nn1_label_f32")
+    return out
+
+
+def nn1_label_tiled(query, ref, ref_idx, ref_labels):
+    """nn1_label on spatially sorted inputs (include/iggt_hip.h): query fp32 [Mq,C] and ref fp32 [Mr,C] ordered along one
+    space-filling curve, ref_idx int32 [Mr] = original position of every ref row (tie-break), ref_labels int32 [Mr] in the sorted
+    order -> labels int32 [Mq] in the sorted query order."""
+    _dev(query, ref, ref_idx, ref_labels)
+    _f32_all(query, ref)
+    assert query.shape[1] == ref.shape[1]
+    for t in (ref_idx, ref_labels):
+        assert t.dtype == torch.int32 and t.is_contiguous() and t.numel() == ref.shape[0]
+    qlo, qhi = hdbscan_tile_boxes(query)
+    rlo, rhi = hdbscan_tile_boxes(ref)
+    out = torch.empty(query.shape[0], dtype=torch.int32, device=query.device)
+    rc = load().iggt_nn1_label_tiled_f32(query.data_ptr(), query.shape[0], qlo.data_ptr(), qhi.data_ptr(), ref.data_ptr(),
+                                         ref.shape[0], rlo.data_ptr(), rhi.data_ptr(), ref.shape[1], ref_idx.data_ptr(),
+                                         ref_labels.data_ptr(), out.data_ptr(), _stream())
+    _check(rc, "iggt_nn1_label_tiled_f32")
     return out
 
 
@@ -910,8 +948,13 @@ def hdbscan_core_dist(x, k, boxes=None):
     return core
 
 
-def hdbscan_nearest_foreign(x, core2, comp, idx, tile_lo, tile_hi, boxes=None):
-    """One Boruvka round (include/iggt_hip.h): arrays ordered by component -> (best_w2 fp32 [M], best_p int32 [M])."""
+def hdbscan_nearest_foreign(x, core2, comp, idx, tile_lo, tile_hi, boxes=None, component_bound=True, nsplit=None):
+    """One Boruvka round (include/iggt_hip.h): arrays ordered by component -> (best_w2 fp32 [M], best_p int32 [M]).
+    component_bound: let workgroups inside one component share the component's best weight so far (points that cannot hold
+    the component's cheapest outgoing edge then report (inf, -1)); False = every point's own cheapest foreign edge.
+    nsplit: workgroups per block of 512 queries (None: by size).  A few blocks hold an outlier whose bound covers nearly every
+    tile; split over the tiles of the walk they stop being the round's critical path.  The planes are folded here under the
+    kernel's own total order (weight, min original index, max original index)."""
     _dev(x, core2, comp, idx, tile_lo, tile_hi)
     _f32_all(x, core2)
     M, C = x.shape
@@ -920,13 +963,27 @@ def hdbscan_nearest_foreign(x, core2, comp, idx, tile_lo, tile_hi, boxes=None):
     assert tile_lo.numel() == (M + 255) // 256 == tile_hi.numel()
     lo, hi = boxes if boxes is not None else hdbscan_tile_boxes(x)
     _f32_all(lo, hi)
-    w2 = torch.empty(M, dtype=torch.float32, device=x.device)
-    bp = torch.empty(M, dtype=torch.int32, device=x.device)
+    ntiles = (M + 255) // 256
+    G = max(1, min(32, ntiles // 32)) if nsplit is None else int(nsplit)
+    w2 = torch.empty(G, M, dtype=torch.float32, device=x.device)
+    bp = torch.empty(G, M, dtype=torch.int32, device=x.device)
+    cbound = None
+    if component_bound:   # component ids are member indices: < M.  0x7f800000 = +inf
+        cbound = torch.full((M,), 0x7f800000, dtype=torch.int32, device=x.device)
     rc = load().iggt_hdbscan_nearest_foreign_f32(x.data_ptr(), core2.data_ptr(), comp.data_ptr(), idx.data_ptr(), tile_lo.data_ptr(),
                                                  tile_hi.data_ptr(), lo.data_ptr(), hi.data_ptr(), M, C, w2.data_ptr(), bp.data_ptr(),
-                                                 _stream())
+                                                 0 if cbound is None else cbound.data_ptr(), G, _stream())
     _check(rc, "iggt_hdbscan_nearest_foreign_f32")
-    return w2, bp
+    if G == 1:
+        return w2[0], bp[0]
+    # fold the planes: smallest weight, then smallest (min, max) pair of original indices -- exact (equal floats compare equal)
+    wmin = w2.amin(0)
+    me = idx.long()[None]
+    other = idx.long()[bp.clamp(min=0).long()]
+    key = torch.where((w2 == wmin[None]) & (bp >= 0), torch.minimum(me, other) * M + torch.maximum(me, other),
+                      torch.full((1, 1), 1 << 62, dtype=torch.int64, device=x.device))
+    sel = key.argmin(0, keepdim=True)
+    return wmin, bp.gather(0, sel)[0].contiguous()
 
 
 def hdbscan_labels_from_mst(eu, ev, ew, n_points, min_cluster_size, eps=0.0, allow_single_cluster=False):

@@ -161,9 +161,35 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
     const int tid = threadIdx.x;
     const int which = tid >> 7, head = (tid >> 3) & 15, j = tid & 7;
     float nmax2 = 0.f;   // largest squared norm this thread's (q|k, head) has produced (static softmax bound)
+    // The affine parameters of this thread's 8 elements live in registers for the whole token loop, and the NEXT token's q / k
+    // (and v) pieces are requested before the current token's arithmetic: one 16-byte load in flight per thread left the kernel
+    // latency-bound (32 KB in flight per CU: 3.4 TB/s of read + write at 44 k tokens).
+    float wreg[8], breg[8];
+    {
+        const float* w = which ? p.kw : p.qw;
+        const float* bb = which ? p.kb : p.qb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            wreg[e] = w[j * 8 + e];
+            breg[e] = bb[j * 8 + e];
+        }
+    }
+    const long qk_off = (long)which * p.C + head * 64 + j * 8;
+    const bool copy_v = p.v_out != nullptr && tid < 128;
+    u32x4 raw_next = {0u, 0u, 0u, 0u}, v_next = {0u, 0u, 0u, 0u};
+    if ((int)blockIdx.x < p.T) {
+        raw_next = *reinterpret_cast<const u32x4*>(p.qkv + (long)blockIdx.x * p.ld_in + qk_off);
+        if (copy_v) v_next = *reinterpret_cast<const u32x4*>(p.qkv + (long)blockIdx.x * p.ld_in + 2 * p.C + tid * 8);
+    }
     for (int t = blockIdx.x; t < p.T; t += gridDim.x) {   // grid-stride over tokens: one norm atomic per block, not per token
-    const bf16_t* src = p.qkv + (long)t * p.ld_in + which * p.C + head * 64 + j * 8;
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(src);
+    const u32x4 raw = raw_next, vv = v_next;
+    {
+        const int tn = t + (int)gridDim.x;
+        if (tn < p.T) {
+            raw_next = *reinterpret_cast<const u32x4*>(p.qkv + (long)tn * p.ld_in + qk_off);
+            if (copy_v) v_next = *reinterpret_cast<const u32x4*>(p.qkv + (long)tn * p.ld_in + 2 * p.C + tid * 8);
+        }
+    }
     float x[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -180,10 +206,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
     for (int e = 0; e < 8; ++e) { const float d = x[e] - mean; q += d * d; }
     q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
     const float rstd = rsqrtf(q * (1.0f / 64) + p.eps);
-    const float* w = which ? p.kw : p.qw;
-    const float* bb = which ? p.kb : p.qb;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = (x[e] - mean) * rstd * w[j * 8 + e] + bb[j * 8 + e];
+    for (int e = 0; e < 8; ++e) x[e] = (x[e] - mean) * rstd * wreg[e] + breg[e];
 
     // RoPE
     const int pt = t % p.P;
@@ -224,8 +248,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
     bf16_t* dst = which ? (p.k_out + hgrp * p.kgs + (long)t * p.ldk + hin * 64) : (p.q_out + (long)t * p.ldq + head * 64);
     *reinterpret_cast<u32x4*>(dst + j * 8) = o;
 
-    if (p.v_out != nullptr && tid < 128) {  // copy v: 1024 x 16 bit = 128 x 16 B; thread -> (head tid/8, slice tid%8)
-        const u32x4 vv = *reinterpret_cast<const u32x4*>(p.qkv + (long)t * p.ld_in + 2 * p.C + tid * 8);
+    if (copy_v) {  // copy v: 1024 x 16 bit = 128 x 16 B; thread -> (head tid/8, slice tid%8)
         const int vh = tid >> 3, vg = vh / p.hg;
         *reinterpret_cast<u32x4*>(p.v_out + vg * p.vgs + (long)t * p.ldv + (vh - vg * p.hg) * 64 + (tid & 7) * 8) = vv;
     }

@@ -141,17 +141,39 @@ __global__ __launch_bounds__(256) void hdb_core_dist_kernel(const float* __restr
 // equal-weight candidate can still win the index tie-break).
 constexpr int QPT = 2;
 
+#ifdef IGGT_HDB_STATS   // developer builds (probes/build_alt.py hdb_stats): where a round's time goes
+__device__ unsigned long long g_hdb_stats[8];
+__device__ unsigned long long g_hdb_blk[131072][4];   // per workgroup: start, end (100 MHz wall clock), steps, tiles processed
+#define HDB_COUNT(i, n) do { if (threadIdx.x == 0) hdb_local[i] += (n); } while (0)
+#define HDB_BEGIN() unsigned long long hdb_local[4] = {0, 0, 0, 0}; const unsigned long long hdb_t0 = wall_clock64()
+#define HDB_END() do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 4; ++i_) atomicAdd(&g_hdb_stats[i_], hdb_local[i_]); \
+        if (blockIdx.x < 131072) { g_hdb_blk[blockIdx.x][0] = hdb_t0; g_hdb_blk[blockIdx.x][1] = wall_clock64(); \
+                                 g_hdb_blk[blockIdx.x][2] = hdb_local[0]; g_hdb_blk[blockIdx.x][3] = hdb_local[2] + hdb_local[3]; } } } while (0)
+#else
+#define HDB_COUNT(i, n) do { } while (0)
+#define HDB_BEGIN() do { } while (0)
+#define HDB_END() do { } while (0)
+#endif
+
 template <int C>
 __global__ __launch_bounds__(256) void hdb_nearest_foreign_kernel(const float* __restrict__ x, const float* __restrict__ core2,
                                                                   const int* __restrict__ comp, const int* __restrict__ idx,
                                                                   const int* __restrict__ tile_lo, const int* __restrict__ tile_hi,
                                                                   const float* __restrict__ box_lo, const float* __restrict__ box_hi,
-                                                                  long M, float* __restrict__ best_w2, int* __restrict__ best_p) {
+                                                                  long M, float* __restrict__ best_w2, int* __restrict__ best_p,
+                                                                  unsigned* __restrict__ comp_bound, int nsplit) {
     __shared__ __attribute__((aligned(16))) float tile[TILE * C];
     __shared__ float tcore[TILE];
     __shared__ int tcomp[TILE], tidx[TILE];
+    __shared__ float red[8];
     const int t = threadIdx.x;
     const int ntiles = (int)((M + TILE - 1) / TILE);
+    // nsplit workgroups share one block of 512 queries: workgroup `part` takes every nsplit-th step of the outward walk (part 0
+    // the own tile, part 1 the next one, ...) and writes its own (best_w2, best_p) plane; the caller folds the planes under the
+    // same total order.  Why: the block-wide vote makes ONE query with a large bound (an outlier: its core distance is the
+    // floor of its bound) drag all 512 through nearly every tile -- a handful of such workgroups ran 200 - 300 ms while the
+    // mean was 4 - 20 ms, and the round waited for them (profiles/r03_postprocess_timing.txt).
+    const int qblock = blockIdx.x / nsplit, part = blockIdx.x - qblock * nsplit;
     float q[QPT][C], qc2[QPT], bw[QPT];
     int qcomp[QPT], qidx[QPT], bp[QPT], blo[QPT], bhi[QPT];
     bool live[QPT];
@@ -164,7 +186,7 @@ __global__ __launch_bounds__(256) void hdb_nearest_foreign_kernel(const float* _
     }
 #pragma unroll
     for (int u = 0; u < QPT; ++u) {
-        const long i = ((long)blockIdx.x * QPT + u) * TILE + t;
+        const long i = ((long)qblock * QPT + u) * TILE + t;
         live[u] = i < M;
 #pragma unroll
         for (int c = 0; c < C; ++c) q[u][c] = live[u] ? x[i * C + c] : 0.f;
@@ -174,7 +196,7 @@ __global__ __launch_bounds__(256) void hdb_nearest_foreign_kernel(const float* _
         bw[u] = live[u] ? INFINITY : -1.f;
         bp[u] = -1;
         blo[u] = bhi[u] = 0x7fffffff;
-        const int qt = blockIdx.x * QPT + u;
+        const int qt = qblock * QPT + u;
         if (qt < ntiles) {
             wg_lo = tile_lo[qt] < wg_lo ? tile_lo[qt] : wg_lo;
             wg_hi = tile_hi[qt] > wg_hi ? tile_hi[qt] : wg_hi;
@@ -185,14 +207,41 @@ __global__ __launch_bounds__(256) void hdb_nearest_foreign_kernel(const float* _
             }
         }
     }
-    const int own = blockIdx.x * QPT;
-    for (int step = 0; step < 2 * ntiles; ++step) {
+    const int own = qblock * QPT;
+    // COMPONENT bound (Boruvka only needs the cheapest outgoing edge per component, not per point): comp_bound[c] holds, as float
+    // bits, the smallest squared weight any workgroup has found so far for an edge out of component c (+inf at launch).  A
+    // workgroup whose queries all belong to ONE component publishes its own minimum there after every tile it processes
+    // (one atomicMin, non-negative floats order like their bit patterns) and reads the value back: candidates and tiles that are
+    // strictly worse than it cannot be the component's minimum and are skipped -- strictly, so that an equal-weight edge with a
+    // smaller index pair still wins the tie-break; the endpoint of the true minimum edge never prunes that edge (its weight is
+    // <= every published value), so the per-component minimum the host takes over best_w2 is unchanged while interior points of
+    // a large component stop after the first foreign tile instead of searching for a far partner nobody needs.  A stale read
+    // only prunes less.  Queries whose own core distance exceeds the bound are dead (mr >= core); a workgroup of dead queries
+    // leaves the loop.  Pruned queries report (inf, -1).
+    const bool single = comp_bound != nullptr && wg_lo == wg_hi;
+    float cb = INFINITY;
+    HDB_BEGIN();
+    if (single) {
+        if (t == 0) red[4] = __uint_as_float(__hip_atomic_load(comp_bound + wg_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        cb = red[4];
+    }
+    for (int step = part; step < 2 * ntiles; step += nsplit) {
         const int tl = outward_tile(own, step, ntiles);
         if (tl < 0) continue;
+        HDB_COUNT(0, 1);
         // skip a tile that lies entirely inside the single component all queries here belong to (block-uniform test)
         if (wg_lo == wg_hi && tile_lo[tl] == wg_lo && tile_hi[tl] == wg_lo) continue;
+        HDB_COUNT(1, 1);
         const float gap2 = box_gap2<C>(qlo, qhi, box_lo + (long)tl * C, box_hi + (long)tl * C);
-        if (!__syncthreads_or(gap2 <= bw[0] || gap2 <= bw[1])) continue;
+        bool need = false;
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+            const float wl = fminf(bw[u], cb);
+            need = need || (live[u] && gap2 <= wl && qc2[u] <= wl);
+        }
+        if (!__syncthreads_or(need)) continue;
+        HDB_COUNT(single ? 2 : 3, 1);
         const long j0 = (long)tl * TILE;
         {
             const long j = j0 + t;
@@ -220,7 +269,7 @@ __global__ __launch_bounds__(256) void hdb_nearest_foreign_kernel(const float* _
                     d2 = fmaf(d, d, d2);
                 }
                 const float w = fmaxf(fmaxf(qc2[u], pc2), d2);
-                if (w > bw[u]) continue;
+                if (w > fminf(bw[u], cb)) continue;
                 const int oj = tidx[jj];
                 const int lo = qidx[u] < oj ? qidx[u] : oj, hi = qidx[u] < oj ? oj : qidx[u];
                 if (w < bw[u] || lo < blo[u] || (lo == blo[u] && hi < bhi[u])) {
@@ -231,13 +280,38 @@ __global__ __launch_bounds__(256) void hdb_nearest_foreign_kernel(const float* _
                 }
             }
         }
+        if (single) {   // publish this workgroup's minimum, fetch the component's
+            float mine = INFINITY;
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) mine = live[u] ? fminf(mine, bw[u]) : mine;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mine = fminf(mine, __shfl_xor(mine, o, 64));
+            if ((t & 63) == 0) red[t >> 6] = mine;
+            __syncthreads();
+            if (t == 0) {
+                const float bm = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+                float gl = __uint_as_float(__hip_atomic_load(comp_bound + wg_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (bm < gl) {
+                    atomicMin(comp_bound + wg_lo, __float_as_uint(bm));
+                    gl = bm;
+                }
+                red[4] = gl;
+            }
+            __syncthreads();
+            cb = red[4];
+            bool alive = false;
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) alive = alive || (live[u] && qc2[u] <= fminf(bw[u], cb));
+            if (!__syncthreads_or(alive)) break;
+        }
     }
+    HDB_END();
 #pragma unroll
     for (int u = 0; u < QPT; ++u) {
-        const long i = ((long)blockIdx.x * QPT + u) * TILE + t;
+        const long i = ((long)qblock * QPT + u) * TILE + t;
         if (live[u]) {
-            best_w2[i] = bw[u];
-            best_p[i] = bp[u];
+            best_w2[(long)part * M + i] = bw[u];
+            best_p[(long)part * M + i] = bp[u];
         }
     }
 }
@@ -259,6 +333,22 @@ int launch_core(const float* x, long M, int k, const float* box_lo, const float*
 
 }  // namespace
 
+#ifdef IGGT_HDB_STATS
+extern "C" int iggt_hdb_block_stats(unsigned long long* out, int nblocks) {   // [nblocks][4]
+    if (nblocks > 131072) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hdb_blk), (size_t)nblocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+
+extern "C" int iggt_hdb_stats(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_hdb_stats), sizeof(g_hdb_stats)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_hdb_stats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 extern "C" int iggt_hdbscan_core_dist_f32(const float* x, long M, int C, int k, const float* box_lo, const float* box_hi,
                                           float* core, void* stream) {
     if (x == nullptr || core == nullptr || box_lo == nullptr || box_hi == nullptr || M <= 0 || M >= (1L << 31) || k < 1 || k > KMAX)
@@ -275,15 +365,17 @@ extern "C" int iggt_hdbscan_core_dist_f32(const float* x, long M, int C, int k, 
 
 extern "C" int iggt_hdbscan_nearest_foreign_f32(const float* x, const float* core2, const int* comp, const int* idx,
                                                 const int* tile_lo, const int* tile_hi, const float* box_lo,
-                                                const float* box_hi, long M, int C, float* best_w2, int* best_p, void* stream) {
+                                                const float* box_hi, long M, int C, float* best_w2, int* best_p,
+                                                unsigned* comp_bound, int nsplit, void* stream) {
     if (x == nullptr || core2 == nullptr || comp == nullptr || idx == nullptr || tile_lo == nullptr || tile_hi == nullptr ||
         box_lo == nullptr || box_hi == nullptr || best_w2 == nullptr || best_p == nullptr || M <= 0 || M >= (1L << 31))
         return -1;
-    const dim3 grid((unsigned)((M + QPT * TILE - 1) / (QPT * TILE))), block(TILE);
+    if (nsplit < 1 || nsplit > 64) return -1;
+    const dim3 grid((unsigned)((M + QPT * TILE - 1) / (QPT * TILE)) * (unsigned)nsplit), block(TILE);
     hipStream_t st = (hipStream_t)stream;
-    if (C == 8) hipLaunchKernelGGL(hdb_nearest_foreign_kernel<8>, grid, block, 0, st, x, core2, comp, idx, tile_lo, tile_hi, box_lo, box_hi, M, best_w2, best_p);
-    else if (C == 3) hipLaunchKernelGGL(hdb_nearest_foreign_kernel<3>, grid, block, 0, st, x, core2, comp, idx, tile_lo, tile_hi, box_lo, box_hi, M, best_w2, best_p);
-    else if (C == 16) hipLaunchKernelGGL(hdb_nearest_foreign_kernel<16>, grid, block, 0, st, x, core2, comp, idx, tile_lo, tile_hi, box_lo, box_hi, M, best_w2, best_p);
+    if (C == 8) hipLaunchKernelGGL(hdb_nearest_foreign_kernel<8>, grid, block, 0, st, x, core2, comp, idx, tile_lo, tile_hi, box_lo, box_hi, M, best_w2, best_p, comp_bound, nsplit);
+    else if (C == 3) hipLaunchKernelGGL(hdb_nearest_foreign_kernel<3>, grid, block, 0, st, x, core2, comp, idx, tile_lo, tile_hi, box_lo, box_hi, M, best_w2, best_p, comp_bound, nsplit);
+    else if (C == 16) hipLaunchKernelGGL(hdb_nearest_foreign_kernel<16>, grid, block, 0, st, x, core2, comp, idx, tile_lo, tile_hi, box_lo, box_hi, M, best_w2, best_p, comp_bound, nsplit);
     else return -2;
     IGGT_CHECK_LAUNCH();
     return 0;

@@ -335,6 +335,146 @@ __global__ __launch_bounds__(256) void nn1_label_kernel(const float* __restrict_
     if (qi < Mq) out[qi] = besti >= 0 ? rlabel[besti] : -1;
 }
 
+// The brute-force search with the samples split over gridDim.y workgroups per query tile: part y scans the contiguous sample range
+// [y * chunk, (y + 1) * chunk) and writes its own (distance, index) plane; the caller folds the planes (smallest distance, then
+// smallest index = the first minimum).  For FEW queries against MANY samples (the usual noise fill: a few thousand noise pixels
+// against 1.35 M labelled ones is 9 query tiles -- 9 workgroups walking 5 292 sample tiles each took 0.49 s).
+template <int CT>
+__global__ __launch_bounds__(256) void nn1_search_split_kernel(const float* __restrict__ qf, long Mq, const float* __restrict__ rf,
+                                                               long Mr, int C, long chunk, float* __restrict__ best_d2,
+                                                               int* __restrict__ best_i) {
+    __shared__ float cand[TILE][CT + 1];
+    const int tid = threadIdx.x;
+    const long qi = (long)blockIdx.x * TILE + tid;
+    float q[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) q[c] = (qi < Mq && c < C) ? qf[qi * C + c] : 0.f;
+    float best = INFINITY;
+    long besti = -1;
+    const long r_begin = (long)blockIdx.y * chunk;
+    const long r_end = (r_begin + chunk) < Mr ? (r_begin + chunk) : Mr;
+    for (long base = r_begin; base < r_end; base += TILE) {
+        __syncthreads();
+        const long r = base + tid;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) cand[tid][c] = (r < r_end && c < C) ? rf[r * C + c] : INFINITY;
+        __syncthreads();
+        const int n = (int)((r_end - base) < TILE ? (r_end - base) : TILE);
+        for (int j = 0; j < n; ++j) {
+            float d2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float d = (c < C) ? cand[j][c] - q[c] : 0.f;
+                d2 += d * d;
+            }
+            if (d2 < best) {
+                best = d2;
+                besti = base + j;
+            }
+        }
+    }
+    if (qi < Mq) {
+        best_d2[(long)blockIdx.y * Mq + qi] = best;
+        best_i[(long)blockIdx.y * Mq + qi] = (int)besti;
+    }
+}
+
+// The same search made local (round 3): queries and labelled samples arrive sorted along one space-filling curve, every tile of
+// 256 consecutive rows with its bounding box.  A workgroup (one query tile) starts at the sample tile whose box is nearest to its
+// own, walks outward in curve order and skips -- after a block-wide vote -- every tile whose box is farther from the query box
+// than each query's best distance so far (the box gap is a lower bound of every pair distance: exact).  "First minimum" of the
+// brute-force kernel = smallest ORIGINAL sample index among equal distances: ridx carries that index, ties are broken on it.
+// At the demo's size (1.35 M pixels, ~10 % noise) the brute-force pass is 1.6e11 pairs; a surface-like cloud leaves a few
+// thousand per query.
+template <int CT>
+__global__ __launch_bounds__(256) void nn1_label_tiled_kernel(const float* __restrict__ qf, long Mq, const float* __restrict__ qblo,
+                                                              const float* __restrict__ qbhi, const float* __restrict__ rf, long Mr,
+                                                              const float* __restrict__ rblo, const float* __restrict__ rbhi, int C,
+                                                              const int* __restrict__ ridx, const int* __restrict__ rlabel,
+                                                              int* __restrict__ out) {
+    __shared__ float cand[TILE][CT + 1];
+    __shared__ int cidx[TILE];
+    __shared__ float sgap[TILE];
+    __shared__ int sarg[TILE];
+    const int tid = threadIdx.x;
+    const long qi = (long)blockIdx.x * TILE + tid;
+    const int nrt = (int)((Mr + TILE - 1) / TILE);
+    float q[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) q[c] = (qi < Mq && c < C) ? qf[qi * C + c] : 0.f;
+    const float* mylo = qblo + (long)blockIdx.x * C;
+    const float* myhi = qbhi + (long)blockIdx.x * C;
+    auto gap2_of = [&](int tl) {
+        float g2 = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float g = fmaxf(fmaxf(mylo[c] - rbhi[(long)tl * C + c], rblo[(long)tl * C + c] - myhi[c]), 0.f);
+            g2 = fmaf(g, g, g2);
+        }
+        return g2;
+    };
+    // seed: the sample tile nearest to the query box (smallest index among equals)
+    {
+        float g = INFINITY;
+        int arg = 0x7fffffff;
+        for (int tl = tid; tl < nrt; tl += TILE) {
+            const float gg = gap2_of(tl);
+            if (gg < g) {
+                g = gg;
+                arg = tl;
+            }
+        }
+        sgap[tid] = g;
+        sarg[tid] = arg;
+        __syncthreads();
+        for (int o = TILE / 2; o > 0; o >>= 1) {
+            if (tid < o) {
+                const float g2 = sgap[tid + o];
+                const int a2 = sarg[tid + o];
+                if (g2 < sgap[tid] || (g2 == sgap[tid] && a2 < sarg[tid])) {
+                    sgap[tid] = g2;
+                    sarg[tid] = a2;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int seed = sarg[0];
+    seed = (seed < 0 || seed >= nrt) ? 0 : seed;
+    float best = qi < Mq ? INFINITY : -1.f;   // dead lanes never ask for a tile
+    int bestpos = -1, besti = 0x7fffffff;
+    for (int step = 0; step < 2 * nrt; ++step) {
+        const int m = (step + 1) >> 1;
+        const int tl = (step & 1) ? seed + m : seed - m;
+        if (tl < 0 || tl >= nrt) continue;
+        const float gap2 = gap2_of(tl);
+        if (!__syncthreads_or(gap2 <= best)) continue;      // (also the barrier that protects the previous tile's readers)
+        const long r0 = (long)tl * TILE;
+        {
+            const long r = r0 + tid;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) cand[tid][c] = c < C ? (r < Mr ? rf[r * C + c] : INFINITY) : 0.f;
+            cidx[tid] = r < Mr ? ridx[r] : 0x7fffffff;
+        }
+        __syncthreads();
+        const int n = (int)((Mr - r0) < TILE ? (Mr - r0) : TILE);
+        for (int j = 0; j < n; ++j) {
+            float d2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float d = cand[j][c] - q[c];
+                d2 += d * d;
+            }
+            const int oi = cidx[j];
+            if (d2 < best || (d2 == best && oi < besti)) {
+                best = d2;
+                bestpos = (int)(r0 + j);
+                besti = oi;
+            }
+        }
+    }
+    if (qi < Mq) out[qi] = bestpos >= 0 ? rlabel[bestpos] : -1;
+}
+
 template <int KMAX>
 int launch_search(const float4* sp, const float* boxes, long M, int ntiles, int k, int* idx, float* d2, hipStream_t st) {
     hipLaunchKernelGGL(knn_search_kernel<KMAX>, dim3((unsigned)ntiles), dim3(256), 0, st, sp, boxes, M, ntiles, k, idx, d2);
@@ -423,6 +563,45 @@ extern "C" int iggt_nn1_label_f32(const float* query, long Mq, const float* ref,
         hipLaunchKernelGGL(nn1_label_kernel<8>, dim3(g), dim3(256), 0, st, query, Mq, ref, Mr, C, ref_labels, out);
     else
         hipLaunchKernelGGL(nn1_label_kernel<16>, dim3(g), dim3(256), 0, st, query, Mq, ref, Mr, C, ref_labels, out);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int iggt_nn1_label_tiled_f32(const float* query, long Mq, const float* qbox_lo, const float* qbox_hi, const float* ref,
+                                        long Mr, const float* rbox_lo, const float* rbox_hi, int C, const int* ref_idx,
+                                        const int* ref_labels, int* out, void* stream) {
+    if (query == nullptr || ref == nullptr || qbox_lo == nullptr || qbox_hi == nullptr || rbox_lo == nullptr || rbox_hi == nullptr ||
+        ref_idx == nullptr || ref_labels == nullptr || out == nullptr)
+        return -1;
+    if (Mq <= 0 || Mr <= 0 || Mr >= (1L << 31) || C <= 0) return -1;
+    if (C > 16) return -3;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned g = (unsigned)((Mq + TILE - 1) / TILE);
+    if (C <= 4)
+        hipLaunchKernelGGL(nn1_label_tiled_kernel<4>, dim3(g), dim3(256), 0, st, query, Mq, qbox_lo, qbox_hi, ref, Mr, rbox_lo, rbox_hi, C,
+                           ref_idx, ref_labels, out);
+    else if (C <= 8)
+        hipLaunchKernelGGL(nn1_label_tiled_kernel<8>, dim3(g), dim3(256), 0, st, query, Mq, qbox_lo, qbox_hi, ref, Mr, rbox_lo, rbox_hi, C,
+                           ref_idx, ref_labels, out);
+    else
+        hipLaunchKernelGGL(nn1_label_tiled_kernel<16>, dim3(g), dim3(256), 0, st, query, Mq, qbox_lo, qbox_hi, ref, Mr, rbox_lo, rbox_hi, C,
+                           ref_idx, ref_labels, out);
+    IGGT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int iggt_nn1_search_split_f32(const float* query, long Mq, const float* ref, long Mr, int C, int nsplit, float* best_d2,
+                                         int* best_idx, void* stream) {
+    if (query == nullptr || ref == nullptr || best_d2 == nullptr || best_idx == nullptr) return -1;
+    if (Mq <= 0 || Mr <= 0 || Mr >= (1L << 31) || C <= 0 || nsplit < 1 || nsplit > 65535) return -1;
+    if (C > 16) return -3;
+    hipStream_t st = (hipStream_t)stream;
+    long chunk = (Mr + nsplit - 1) / nsplit;
+    chunk = (chunk + TILE - 1) / TILE * TILE;          // whole tiles: a part's range starts on a tile boundary
+    const dim3 g((unsigned)((Mq + TILE - 1) / TILE), (unsigned)nsplit);
+    if (C <= 4) hipLaunchKernelGGL(nn1_search_split_kernel<4>, g, dim3(256), 0, st, query, Mq, ref, Mr, C, chunk, best_d2, best_idx);
+    else if (C <= 8) hipLaunchKernelGGL(nn1_search_split_kernel<8>, g, dim3(256), 0, st, query, Mq, ref, Mr, C, chunk, best_d2, best_idx);
+    else hipLaunchKernelGGL(nn1_search_split_kernel<16>, g, dim3(256), 0, st, query, Mq, ref, Mr, C, chunk, best_d2, best_idx);
     IGGT_CHECK_LAUNCH();
     return 0;
 }

@@ -10,11 +10,14 @@ The algorithm (Campello, Moulavi, Sander 2013; cluster_selection_epsilon: Malzer
      jumping are torch index operations on M-element arrays
   Both kernels are exhaustive searches made local: the points are first ordered along a Morton curve over their first three
   principal axes (`spatial_order`), every 256-point tile carries its bounding box, and a tile that is provably too far is skipped.
+  A round only needs the cheapest outgoing edge per COMPONENT: workgroups inside one component share the best weight found so far
+  and drop everything strictly worse (exact; interior points of a large component stop after their first foreign tile).
   3. dendrogram -> condensed tree -> excess-of-mass selection -> epsilon -> labels: a walk over the M - 1 edges on the host
      (csrc/hdbscan_tree.hip, pure host code, checked against scikit-learn on the CPU by tests/test_hdbscan.py)
 Labels agree with scikit-learn's up to the numbering of the clusters (the numbering follows the orientation of the spanning-tree
 edges, which no two implementations share) and up to fp32-vs-fp64 ties on borderline points.  No CPU fallback: the points must be on
 the GPU."""
+import os
 from typing import Optional
 
 import numpy as np
@@ -61,6 +64,9 @@ def _segment_min(values: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
     return torch.segment_reduce(values, "min", lengths=counts, unsafe=True)
 
 
+COMPONENT_BOUND = os.environ.get("IGGT_HDB_COMPONENT_BOUND", "1") != "0"   # A/B switch of the per-component pruning (csrc/hdbscan.hip)
+
+
 def mutual_reachability_mst(x: torch.Tensor, min_samples: int, _kernels=None):
     """x fp32 [M, C] on the GPU -> (eu, ev int64 [M - 1], ew fp32 [M - 1]) spanning-tree edges (original indices, weights =
     mutual-reachability distances) and the core distances fp32 [M].
@@ -87,8 +93,12 @@ def mutual_reachability_mst(x: torch.Tensor, min_samples: int, _kernels=None):
         xs, c2s = x[order].contiguous(), core2[order].contiguous()
         ntile = (M + 255) // 256
         padded = torch.cat([comps, comps[-1:].expand(ntile * 256 - M)]).view(ntile, 256)
+        extra = {} if _kernels is not None else {"component_bound": COMPONENT_BOUND}
         w2, bp = nearest_foreign(xs, c2s, comps.int().contiguous(), order.int().contiguous(),
-                                 padded.amin(1).int().contiguous(), padded.amax(1).int().contiguous(), _C.hdbscan_tile_boxes(xs))
+                                 padded.amin(1).int().contiguous(), padded.amax(1).int().contiguous(), _C.hdbscan_tile_boxes(xs),
+                                 **extra)
+        # (with the component bound a point that cannot hold its component's cheapest edge reports (inf, -1): bp = -1 indexes the
+        #  last position below, harmlessly -- only entries with w2 == the component's finite minimum are looked at)
         oi, oj = order, order[bp.long()]
         lo, hi = torch.minimum(oi, oj), torch.maximum(oi, oj)
         # cheapest outgoing edge of every component under the total order (weight, lo, hi): components are runs of `comps`

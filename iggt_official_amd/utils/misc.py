@@ -114,6 +114,9 @@ def _hdbscan(pix: torch.Tensor, eps, min_samples, min_cluster_size) -> np.ndarra
     return hdbscan_labels(pix, min_cluster_size, min_samples, float(eps) if eps is not None else 0.0, allow_single_cluster=False)
 
 
+FILL_TILED_MIN = 1e11   # noise x labelled pairs; below it the brute-force kernel (~1e12 pairs / s) beats sorting the pixels first
+
+
 def fill_noise_labels(pixels: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     """labels int [M] with -1 = noise -> every noise pixel takes the label of its nearest labelled pixel in feature space
     (all zeros when nothing is labelled), reference misc.py:128-144."""
@@ -124,7 +127,21 @@ def fill_noise_labels(pixels: torch.Tensor, labels: torch.Tensor) -> torch.Tenso
         return labels
     if nbad == labels.numel():
         return torch.zeros_like(labels)
-    labels[bad] = _C.nn1_label(pixels[bad].contiguous(), pixels[~bad].contiguous(), labels[~bad].contiguous())
+    if float(nbad) * float(labels.numel() - nbad) < FILL_TILED_MIN or not torch.isfinite(pixels).all():
+        labels[bad] = _C.nn1_label(pixels[bad].contiguous(), pixels[~bad].contiguous(), labels[~bad].contiguous())
+        return labels
+    # Large inputs: the same exact result from a local search.  All pixels are ordered along one Morton curve over their first
+    # three principal axes (the order the HDBSCAN kernels use); noise pixels and labelled pixels keep that order, the kernel
+    # skips sample tiles whose bounding box is farther than the best distance so far.  Ties go to the smallest pixel index,
+    # like the first minimum of the brute-force kernel over pixels[~bad].
+    from . import hdbscan as _hd
+
+    perm = _hd.spatial_order(pixels)
+    badp = bad[perm]
+    q_order, r_order = perm[badp], perm[~badp]
+    got = _C.nn1_label_tiled(pixels[q_order].contiguous(), pixels[r_order].contiguous(), r_order.int().contiguous(),
+                             labels[r_order].contiguous())
+    labels[q_order] = got
     return labels
 
 

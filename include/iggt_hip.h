@@ -352,6 +352,20 @@ int iggt_stretch3_f32(float* img, long M, const float* lohi, void* stream);
  * clustering step (NearestNeighbors(n_neighbors=1), misc.py:130-144). */
 int iggt_nn1_label_f32(const float* query, long Mq, const float* ref, long Mr, int C, const int* ref_labels, int* out,
                        void* stream);
+/* The search behind it with the samples split over nsplit workgroups per tile of 256 queries (ABI v22): part s scans a contiguous
+ * range of ceil(Mr / nsplit) rows (rounded up to whole tiles of 256) and writes best_d2 [nsplit][Mq] (inf: empty range) and
+ * best_idx [nsplit][Mq] (row of ref, -1: none) -- the first minimum inside its range.  The caller takes the smallest distance, then
+ * the smallest index, over the planes: few queries against many samples no longer run as a handful of long workgroups. */
+int iggt_nn1_search_split_f32(const float* query, long Mq, const float* ref, long Mr, int C, int nsplit, float* best_d2,
+                              int* best_idx, void* stream);
+/* The same result from a local search (ABI v22).  query [Mq][C] and ref [Mr][C] are given ordered along ONE space-filling curve
+ * (any order is exact; a spatial one lets far tiles be skipped), with the per-channel bounding box of every tile of 256
+ * consecutive rows: qbox_lo / qbox_hi [ceil(Mq / 256)][C], rbox_lo / rbox_hi [ceil(Mr / 256)][C].  ref_idx [Mr]: the position
+ * each ref row had in the caller's original order -- among equal distances the smallest ref_idx wins, which reproduces the
+ * "first minimum" of iggt_nn1_label_f32 on the unsorted arrays.  ref_labels [Mr] in the given (sorted) order; out [Mq] likewise. */
+int iggt_nn1_label_tiled_f32(const float* query, long Mq, const float* qbox_lo, const float* qbox_hi, const float* ref, long Mr,
+                             const float* rbox_lo, const float* rbox_hi, int C, const int* ref_idx, const int* ref_labels,
+                             int* out, void* stream);
 
 /* ---- track head: the query_points path of IGGT.forward (csrc/track.hip; reference iggt/models/vggt.py:220-227,
  *      iggt/heads/track_head.py:75-109, iggt/heads/track_modules/) ------------------------------------------------------ */
@@ -410,10 +424,18 @@ int iggt_hdbscan_core_dist_f32(const float* x, long M, int C, int k, const float
  * ties are broken on (min, max) of the ORIGINAL indices), tile_lo / tile_hi [ceil(M / 256)] (smallest / largest component id inside
  * each 256-position tile), box_lo / box_hi [ceil(M / 256)][C] (bounding boxes of the tiles, as above).  Writes, per position, the
  * squared weight best_w2 (inf: no other component) and the POSITION best_p of the cheapest partner outside its own component
- * (-1: none). */
+ * (-1: none).
+ * comp_bound (ABI v22; nullable): [max component id + 1] words the caller fills with 0x7f800000 (+inf) before the launch.  The
+ * round only needs the cheapest outgoing edge PER COMPONENT: workgroups whose points share one component publish their best
+ * squared weight here (atomic minimum on the float bits) and skip candidates strictly worse than the published value, so
+ * points in the interior of a large component stop early.  With it, best_w2 / best_p of a point may read (inf, -1) although a
+ * foreign point exists; the minimum over each component under the order (weight, min index, max index) is unchanged.
+ * nsplit (ABI v22; 1 .. 64): every block of 512 positions is searched by nsplit workgroups, each over every nsplit-th tile of the
+ * walk; best_w2 / best_p are then [nsplit][M] planes (plane s = what workgroup s of each block found) and the caller takes,
+ * per position, the minimum over the planes under the same total order.  1 = one plane, the result itself. */
 int iggt_hdbscan_nearest_foreign_f32(const float* x, const float* core2, const int* comp, const int* idx, const int* tile_lo,
                                      const int* tile_hi, const float* box_lo, const float* box_hi, long M, int C,
-                                     float* best_w2, int* best_p, void* stream);
+                                     float* best_w2, int* best_p, unsigned* comp_bound, int nsplit, void* stream);
 /* HOST function (no GPU needed): spanning tree edges (eu[e], ev[e], ew[e]), e < n_points - 1, of the mutual-reachability graph
  * -> flat HDBSCAN labels [n_points] (-1 = noise; clusters numbered like scikit-learn's): single-linkage dendrogram, condensed
  * tree for min_cluster_size, excess-of-mass selection, cluster_selection_epsilon, allow_single_cluster.  Returns 0, or a

@@ -13,6 +13,7 @@ VARIANTS = {
     "attn_noslp": {"attention_v3.hip": ["-fno-slp-vectorize"]},
     "attn_nopin": {"attention_v3.hip": ["-DIGGT_ATTN_NO_PIN"]},
     "attn_nopin_noslp": {"attention_v3.hip": ["-DIGGT_ATTN_NO_PIN", "-fno-slp-vectorize"]},
+    "hdb_stats": {"hdbscan.hip": ["-DIGGT_HDB_STATS"]},   # per-round tile counters, read by probes/hdbscan_profile.py
 }
 
 

@@ -46,14 +46,53 @@ def timed_cd(*a):
     return out
 
 
+def hdb_stats():   # only in the IGGT_HIP_LIB=probes/lib_alt/hdb_stats.so build
+    import ctypes
+
+    lib = _C.load()
+    if not hasattr(lib, "iggt_hdb_stats"):
+        return None
+    buf = (ctypes.c_ulonglong * 8)()
+    lib.iggt_hdb_stats(buf, 1)
+    return list(buf)
+
+
 def timed_nf(*a):
-    dt, out = sync_time(lambda: orig_nf(*a))
-    rounds.append((dt, int(torch.unique(a[2]).numel())))
+    hdb_stats()
+    dt, out = sync_time(lambda: orig_nf(*a, component_bound=hd.COMPONENT_BOUND))   # IGGT_HDB_COMPONENT_BOUND=0: off
+    st = hdb_stats()
+    if st is not None:
+        import ctypes
+        import numpy as np
+
+        nb = ((a[0].shape[0] + 511) // 512) * max(1, min(32, ((a[0].shape[0] + 255) // 256) // 32))   # x nsplit (_C.py)
+        buf = (ctypes.c_ulonglong * (4 * nb))()
+        _C.load().iggt_hdb_block_stats(buf, nb)
+        blk = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 4).astype(np.float64)
+        t0 = blk[:, 0].min()
+        dur = (blk[:, 1] - blk[:, 0]) / 100.0            # us (100 MHz)
+        start = (blk[:, 0] - t0) / 100.0
+        order = np.argsort(-dur)[:5]
+        st = st + [f"block durations us: mean {dur.mean():.0f} median {np.median(dur):.0f} max {dur.max():.0f}; last start at {start.max():.0f} us, "
+                   f"last end at {((blk[:, 1] - t0) / 100.0).max():.0f} us; slowest blocks (id, us, steps, tiles): "
+                   + ", ".join(f"({i}, {dur[i]:.0f}, {int(blk[i, 2])}, {int(blk[i, 3])})" for i in order)
+                   + f"; us per step of blocks with no tile: {np.mean(dur[blk[:, 3] == 0] / np.maximum(blk[blk[:, 3] == 0, 2], 1)) if (blk[:, 3] == 0).any() else float('nan'):.2f}"
+                   + f"; corr(duration, tiles) {np.corrcoef(dur, blk[:, 3])[0, 1]:.2f}"]
+    comps = a[2]
+    tl, th = a[4], a[5]
+    single_tiles = int((tl == th).sum())
+    pruned = int(torch.isinf(out[0]).sum())
+    rounds.append((dt, int(torch.unique(comps).numel()), st, single_tiles, int(tl.numel()), pruned))
     return out
 
 
 dt, _ = sync_time(lambda: hd.mutual_reachability_mst(x, 100, _kernels=(timed_cd, timed_nf)))
 print(f"mutual_reachability_mst: {dt:.3f} s = core pass {sum(cores):.3f} s + {len(rounds)} Boruvka rounds, kernels "
       f"{sum(r[0] for r in rounds):.3f} s + glue")
-for i, (dt, nc) in enumerate(rounds):
-    print(f"  round {i:2d}: {nc:8d} components, kernel {dt:.3f} s")
+for i, (dt, nc, st, stl, ntl, pruned) in enumerate(rounds):
+    print(f"  round {i:2d}: {nc:8d} components, kernel {dt:.3f} s; single-component tiles {stl} of {ntl}; points reporting no edge {pruned}")
+    if st is not None:
+        print(f"            steps {st[0]}, not skipped as own component {st[1]}, tiles processed by single-component workgroups "
+              f"{st[2]}, by mixed ones {st[3]}  (a processed tile = 256 x 512 pairs)")
+        if len(st) > 8:
+            print("            " + st[8])

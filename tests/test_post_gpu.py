@@ -123,6 +123,35 @@ def test_nn1_label_first_minimum():
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("kind", ["surface", "uniform", "ties"])
+def test_fill_noise_labels_tiled_equals_brute_force(kind):
+    """The local search behind fill_noise_labels on large inputs (sorted pixels, per-tile boxes, far tiles skipped) returns
+    exactly what the brute-force kernel returns, ties included (smallest pixel index among equal distances)."""
+    g = torch.Generator().manual_seed(11)
+    M, C = 60_000, 8
+    if kind == "surface":          # points near a 2-D sheet in feature space, like part features of a scene
+        uv = torch.rand(M, 2, generator=g)
+        basis = torch.randn(2, C, generator=g)
+        px = uv @ basis + 0.01 * torch.randn(M, C, generator=g)
+    elif kind == "uniform":
+        px = torch.rand(M, C, generator=g)
+    else:                          # a coarse grid: many exactly equal distances
+        px = torch.randint(0, 4, (M, C), generator=g).float()
+    labels = torch.randint(0, 7, (M,), generator=g)
+    labels[torch.rand(M, generator=g) < 0.15] = -1
+    px, labels = px.cuda(), labels.cuda()
+    bad = labels < 0
+    want = labels.int().clone()
+    want[bad] = _C.nn1_label(px[bad].contiguous(), px[~bad].contiguous(), labels[~bad].int().contiguous())
+    old = misc.FILL_TILED_MIN
+    try:
+        misc.FILL_TILED_MIN = 1
+        got = misc.fill_noise_labels(px, labels)
+    finally:
+        misc.FILL_TILED_MIN = old
+    assert torch.equal(got, want), int((got != want).sum())
+
+
 def test_alias_module_exports():
     import iggt.utils.misc as alias
 
@@ -184,6 +213,34 @@ def test_hdbscan_spanning_tree_and_labels_match_scikit_learn():
         report(f"post/hdbscan/{name}", dict(points=len(X), clusters=int(got.max() + 1), clusters_ref=int(ref.max() + 1), ari=ari,
                                             noise=int((got < 0).sum()), noise_ref=int((ref < 0).sum())))
         assert got.max() == ref.max() and ari > 0.99, (name, ari)
+
+
+def test_hdbscan_component_bound_keeps_the_spanning_tree():
+    """The per-component pruning of the Boruvka kernel (csrc/hdbscan.hip: workgroups inside one component share the best weight
+    found so far) must not change a single edge: same (u, v, w) set with the bound on and off, on clustered and on uniform data,
+    including duplicates (equal weights: the index tie-break decides)."""
+    from iggt_official_amd.utils import hdbscan as hd
+
+    rng = np.random.default_rng(5)
+    dup = _blobs(rng, 4000, 4, 8, 0.05)
+    dup[100:1100] = dup[2000:3000]                                     # 1 000 exact duplicates
+    cases = [("blobs", _blobs(rng, 20000, 6, 8, 0.05), 20), ("uniform", rng.uniform(size=(9000, 8)).astype(np.float32), 5),
+             ("duplicates", dup, 10), ("demo k", _blobs(rng, 30000, 3, 8, 0.02), 100)]
+    old = hd.COMPONENT_BOUND
+    try:
+        for name, X, k in cases:
+            x = torch.from_numpy(X).cuda()
+            trees = []
+            for on in (False, True):
+                hd.COMPONENT_BOUND = on
+                eu, ev, ew, _ = hd.mutual_reachability_mst(x, k)
+                lo, hi = torch.minimum(eu, ev), torch.maximum(eu, ev)
+                order = torch.argsort(lo * len(X) + hi)
+                trees.append((lo[order].cpu(), hi[order].cpu(), ew[order].cpu()))
+            for a, b in zip(trees[0], trees[1]):
+                assert torch.equal(a, b), name
+    finally:
+        hd.COMPONENT_BOUND = old
 
 
 def test_cluster_features_to_masks_mv_runs_hdbscan_on_the_gpu():
