@@ -44,7 +44,10 @@ int pick_tile(int B, int H, int Nq, int code) {
     const long w256 = (long)B * H * ((Nq + 255) / 256);
     const int pad256 = ((Nq + 255) / 256) * 256, pad128 = ((Nq + 127) / 128) * 128;
     const bool small_grid = w256 * 10 < (long)device_cus() * 2 * 12;
-    const bool pads_more = (long)pad256 * 100 > (long)pad128 * 105;
+    // (b) only while the grid is a few rounds: from four full rounds of 256-row tiles on, the big tile wins despite its padding
+    // (frame attention of 32 views, 32 x 16 sequences of 1 374 tokens = 3 072 tiles: 326 vs 346 us static, 337 vs 350 us
+    // online-max, probes/attn_frame_codes.py; 4 views: 66 vs 61 us, the small tile stays)
+    const bool pads_more = (long)pad256 * 100 > (long)pad128 * 105 && w256 < (long)device_cus() * 2 * 4;
     return (small_grid || pads_more) ? 5128 : 6256;
 }
 
