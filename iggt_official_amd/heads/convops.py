@@ -184,7 +184,7 @@ def run(pc: PackedConv, x: torch.Tensor, *, out: Optional[torch.Tensor] = None, 
     if prec == 2 and flops < PREC2_MIN_FLOPS:
         prec = 3          # small problem: the two correction launches cost more than the third MFMA pass
     w_a, w_b = pc.planes(prec)
-    with profiling.region("conv", flops):
+    with profiling.region("conv", (flops, 2 if prec == 2 else 3)):    # (algorithmic FLOPs, MFMA passes per product)
         _C.conv2d_nhwc(x, w_a, w_b, pc.bias, out, KH=pc.KH, KW=pc.KW, stride=pc.stride, pad_y=pc.pad_y,
                        pad_x=pc.pad_x, Ho=Ho, Wo=Wo, res=res, res2=res2, relu_in=relu_in, relu_res=relu_res, act=act,
                        prec=prec, Cin=pc.Cin, Cout=pc.Cout, cout_phys=pc.cout_phys, ps=pc.ps,
