@@ -23,6 +23,7 @@
 //     bound is skipped after a block-wide vote -- exact (the box gap is a lower bound of every pair distance), and what turns
 //     the M^2 passes into a neighbourhood search on data that is not uniformly spread in all C dimensions.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "../../include/iggt_hip.h"
@@ -72,21 +73,25 @@ IGGT_DEVINL int outward_tile(int own, int step, int ntiles) {
 // Points are given SORTED along a Morton curve over their first three principal axes (iggt_official_amd/utils/hdbscan.py), with the
 // bounding box of every 256-point tile (box_lo / box_hi [ntiles][C]).  A candidate tile whose box is farther from the query tile's
 // box than every query's current k-th distance cannot change any result and is skipped (block-wide vote, exact).
-template <int C>
-__global__ __launch_bounds__(256) void hdb_core_dist_kernel(const float* __restrict__ x, long M, int k,
-                                                            const float* __restrict__ box_lo, const float* __restrict__ box_hi,
-                                                            float* __restrict__ core) {
+// QT = queries (threads) per workgroup: 256, or 128 for k > 48 -- the heaps of 256 queries at k = 100 are 100 KB of LDS, ONE
+// workgroup per CU, and the sift-down of a replacement is a chain of dependent LDS reads that nothing else on the SIMD hides; half
+// the queries per workgroup fit three workgroups per CU.  The candidate tiles stay 256 points; the walk starts at the 256-point tile
+// that contains the queries and uses its box (a superset of theirs: a valid, slightly looser gap).
+template <int C, int QT>
+__global__ __launch_bounds__(QT) void hdb_core_dist_kernel(const float* __restrict__ x, long M, int k,
+                                                           const float* __restrict__ box_lo, const float* __restrict__ box_hi,
+                                                           float* __restrict__ core) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem;                 // [TILE][C]: a candidate's C coordinates are contiguous (one or two 16-byte broadcast reads)
-    float* heap = smem + C * TILE;      // [k][TILE]: per-query max-heap of the k smallest squared distances, node-major
+    float* heap = smem + C * TILE;      // [k][QT]: per-query max-heap of the k smallest squared distances, node-major
     const int t = threadIdx.x;
-    const int own = blockIdx.x;
+    const int own = (int)(((long)blockIdx.x * QT) / TILE);
     const int ntiles = (int)((M + TILE - 1) / TILE);
-    const long i = (long)own * TILE + t;
+    const long i = (long)blockIdx.x * QT + t;
     float q[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) q[c] = i < M ? x[i * C + c] : 0.f;
-    for (int s = 0; s < k; ++s) heap[s * TILE + t] = INFINITY;
+    for (int s = 0; s < k; ++s) heap[s * QT + t] = INFINITY;
     float cur_max = i < M ? INFINITY : -1.f;     // dead lanes never ask for a tile
     for (int step = 0; step < 2 * ntiles; ++step) {
         const int tl = outward_tile(own, step, ntiles);
@@ -94,10 +99,10 @@ __global__ __launch_bounds__(256) void hdb_core_dist_kernel(const float* __restr
         const float gap2 = box_gap2<C>(box_lo + (long)own * C, box_hi + (long)own * C, box_lo + (long)tl * C, box_hi + (long)tl * C);
         if (!__syncthreads_or(gap2 < cur_max)) continue;      // (also the barrier that protects the previous tile's readers)
         const long j0 = (long)tl * TILE;
-        {
-            const long j = j0 + t;
+        for (int sidx = t; sidx < TILE; sidx += QT) {
+            const long j = j0 + sidx;
 #pragma unroll
-            for (int c = 0; c < C; ++c) tile[t * C + c] = j < M ? x[j * C + c] : INFINITY;   // padding: distance inf
+            for (int c = 0; c < C; ++c) tile[sidx * C + c] = j < M ? x[j * C + c] : INFINITY;   // padding: distance inf
         }
         __syncthreads();
         const int nj = (int)((M - j0) < TILE ? (M - j0) : TILE);
@@ -115,15 +120,15 @@ __global__ __launch_bounds__(256) void hdb_core_dist_kernel(const float* __restr
                 for (;;) {
                     const int l = 2 * n + 1;
                     if (l >= k) break;
-                    const float lv = heap[l * TILE + t];
-                    const float rv = (l + 1 < k) ? heap[(l + 1) * TILE + t] : -1.f;
+                    const float lv = heap[l * QT + t];
+                    const float rv = (l + 1 < k) ? heap[(l + 1) * QT + t] : -1.f;
                     const int cn = rv > lv ? l + 1 : l;
                     const float cv = fmaxf(lv, rv);
                     if (cv <= d2) break;
-                    heap[n * TILE + t] = cv;
+                    heap[n * QT + t] = cv;
                     n = cn;
                 }
-                heap[n * TILE + t] = d2;
+                heap[n * QT + t] = d2;
                 cur_max = heap[t];
             }
         }
@@ -316,19 +321,31 @@ __global__ __launch_bounds__(256) void hdb_nearest_foreign_kernel(const float* _
     }
 }
 
-template <int C>
-int launch_core(const float* x, long M, int k, const float* box_lo, const float* box_hi, float* core, hipStream_t stream) {
-    const size_t lds = (size_t)(C + k) * TILE * sizeof(float);
+template <int C, int QT>
+int launch_core_qt(const float* x, long M, int k, const float* box_lo, const float* box_hi, float* core, hipStream_t stream) {
+    const size_t lds = ((size_t)C * TILE + (size_t)k * QT) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void*)hdb_core_dist_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)((C + KMAX) * TILE * sizeof(float)));
+        const hipError_t e = hipFuncSetAttribute((const void*)hdb_core_dist_kernel<C, QT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)(((size_t)C * TILE + (size_t)KMAX * QT) * sizeof(float)));
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(hdb_core_dist_kernel<C>, dim3((unsigned)((M + TILE - 1) / TILE)), dim3(TILE), lds, stream, x, M, k, box_lo,
+    hipLaunchKernelGGL((hdb_core_dist_kernel<C, QT>), dim3((unsigned)((M + QT - 1) / QT)), dim3(QT), lds, stream, x, M, k, box_lo,
                        box_hi, core);
     return 0;
+}
+
+template <int C>
+int launch_core(const float* x, long M, int k, const float* box_lo, const float* box_hi, float* core, hipStream_t stream) {
+    static int qt_env = -1;
+    if (qt_env < 0) {
+        const char* e = getenv("IGGT_HDB_CORE_QT");   // A/B switch: 128 / 256 queries per workgroup (default: by k)
+        qt_env = e ? atoi(e) : 0;
+    }
+    const bool small = qt_env == 128 || (qt_env != 256 && k > 48);
+    return small ? launch_core_qt<C, 128>(x, M, k, box_lo, box_hi, core, stream)
+                 : launch_core_qt<C, 256>(x, M, k, box_lo, box_hi, core, stream);
 }
 
 }  // namespace

@@ -147,5 +147,10 @@ def hdbscan_labels(x: torch.Tensor, min_cluster_size: int, min_samples: Optional
     if M == 1:
         return np.full(1, -1, dtype=np.int32)
     eu, ev, ew, _ = mutual_reachability_mst(x, k, _kernels)
+    # The host walk starts with a stable sort of the edges by weight -- 0.1 s of indirect comparisons on one core at 1.35 M edges.
+    # Handing it the edges already stably sorted (device radix sort) leaves its result unchanged (equal weights keep their order
+    # under both sorts) and turns its own sort into a linear pass.
+    srt = torch.sort(ew, stable=True).indices
+    eu, ev, ew = eu[srt], ev[srt], ew[srt]
     return _C.hdbscan_labels_from_mst(eu.cpu().numpy(), ev.cpu().numpy(), ew.cpu().numpy(), M, int(min_cluster_size),
                                       float(cluster_selection_epsilon or 0.0), allow_single_cluster)
