@@ -13,7 +13,13 @@ VARIANTS = {
     "attn_noslp": {"attention_v3.hip": ["-fno-slp-vectorize"]},
     "attn_nopin": {"attention_v3.hip": ["-DIGGT_ATTN_NO_PIN"]},
     "attn_nopin_noslp": {"attention_v3.hip": ["-DIGGT_ATTN_NO_PIN", "-fno-slp-vectorize"]},
-    "hdb_stats": {"hdbscan.hip": ["-DIGGT_HDB_STATS"]},   # per-round tile counters, read by probes/hdbscan_profile.py
+    "hdb_stats": {"hdbscan.hip": ["-DIGGT_HDB_STATS"]},
+    # LLVM scheduling strategies on the three matrix-pipe kernels (timed by probes/sched_ab.py); iterative-ilp does not get
+    # through attention_v3.hip (compiler error)
+    **{f"sched_{n}": {f: fl for f in ("attention_v3.hip", "gemm_bf16_t256.hip", "conv3x3_halo.hip")}
+       for n, fl in {"maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+                     "nopostra": ["-mllvm", "-enable-post-misched=false"],
+                     "postbu": ["-mllvm", "-misched-postra-direction=bottomup"]}.items()},   # per-round tile counters, read by probes/hdbscan_profile.py
 }
 
 
@@ -21,7 +27,7 @@ def main():
     build_ext.build(verbose=False)
     out_dir = os.path.join(ROOT, "probes", "lib_alt")
     os.makedirs(out_dir, exist_ok=True)
-    names = sys.argv[1:] or list(VARIANTS)
+    names = sys.argv[1:] or [n for n in VARIANTS if not n.startswith("sched_")]
     for name in names:
         objs, procs = [], []
         for src in build_ext.sources():
