@@ -783,18 +783,24 @@ def nn1_label(query, ref, ref_labels):
         rc = load().iggt_nn1_search_split_f32(query.data_ptr(), Mq, ref.data_ptr(), Mr, ref.shape[1], nsplit, d2.data_ptr(),
                                               bi.data_ptr(), _stream())
         _check(rc, "iggt_nn1_search_split_f32")
-        # planes cover increasing index ranges: the first plane holding the smallest distance holds the first minimum
-        # (strict < inside a plane keeps the first one there; a NaN distance never wins, like in the one-pass kernel)
-        dmin = d2.amin(0, keepdim=True)
-        hit = (d2 == dmin) & (bi >= 0)
-        first = torch.where(hit.any(0), hit.int().argmax(0), torch.zeros((), dtype=torch.int64, device=query.device))
-        idx = bi.gather(0, first[None])[0].long()
+        idx = fold_nn1_planes(d2, bi)
         return torch.where(idx >= 0, ref_labels[idx.clamp(min=0)], torch.full((), -1, dtype=torch.int32, device=query.device))
     out = torch.empty(Mq, dtype=torch.int32, device=query.device)
     rc = load().iggt_nn1_label_f32(query.data_ptr(), Mq, ref.data_ptr(), Mr, ref.shape[1], ref_labels.data_ptr(), out.data_ptr(),
                                    _stream())
     _check(rc, "iggt_nn1_label_f32")
     return out
+
+
+def fold_nn1_planes(d2, bi):
+    """Planes of iggt_nn1_search_split_f32 (d2 fp32 [S, Mq] best squared distance of sample range s, bi int32 [S, Mq] its row, -1 =
+    empty range) -> int64 [Mq] row of the FIRST minimum over all samples (-1: none).  The planes cover increasing index ranges and
+    each holds the first minimum of its range (strict < in the kernel), so the first plane that attains the smallest distance
+    holds it.  Pure torch (CPU test: tests/test_hdbscan.py)."""
+    dmin = d2.amin(0, keepdim=True)
+    hit = (d2 == dmin) & (bi >= 0)
+    first = torch.where(hit.any(0), hit.int().argmax(0), torch.zeros((), dtype=torch.int64, device=d2.device))
+    return bi.gather(0, first[None])[0].long()
 
 
 def nn1_label_tiled(query, ref, ref_idx, ref_labels):
@@ -974,14 +980,22 @@ def hdbscan_nearest_foreign(x, core2, comp, idx, tile_lo, tile_hi, boxes=None, c
                                                  tile_hi.data_ptr(), lo.data_ptr(), hi.data_ptr(), M, C, w2.data_ptr(), bp.data_ptr(),
                                                  0 if cbound is None else cbound.data_ptr(), G, _stream())
     _check(rc, "iggt_hdbscan_nearest_foreign_f32")
+    return fold_foreign_planes(w2, bp, idx)
+
+
+def fold_foreign_planes(w2, bp, idx):
+    """Planes of one Boruvka round (iggt_hdbscan_nearest_foreign_f32 with nsplit > 1: w2 fp32 [G, M] squared weights, bp int32
+    [G, M] partner positions, -1 = none) -> (w2 [M], bp [M]): per position the smallest weight, then the smallest (min, max) pair of
+    ORIGINAL indices (idx int [M]: original index of every position) -- the kernel's own total order, exact (equal floats compare
+    equal).  Pure torch: tests/test_hdbscan.py checks it on the CPU against a per-position scan."""
+    G, M = w2.shape
     if G == 1:
         return w2[0], bp[0]
-    # fold the planes: smallest weight, then smallest (min, max) pair of original indices -- exact (equal floats compare equal)
     wmin = w2.amin(0)
     me = idx.long()[None]
     other = idx.long()[bp.clamp(min=0).long()]
     key = torch.where((w2 == wmin[None]) & (bp >= 0), torch.minimum(me, other) * M + torch.maximum(me, other),
-                      torch.full((1, 1), 1 << 62, dtype=torch.int64, device=x.device))
+                      torch.full((1, 1), 1 << 62, dtype=torch.int64, device=w2.device))
     sel = key.argmin(0, keepdim=True)
     return wmin, bp.gather(0, sel)[0].contiguous()
 

@@ -112,3 +112,45 @@ def test_product_refuses_cpu_points():
 
     with pytest.raises(_C.HipExtensionError):
         hd.hdbscan_labels(torch.zeros(50, 8), 5)
+
+
+def test_plane_folds_match_a_per_position_scan():
+    """Host side of the load-balanced searches (iggt_official_amd/_C.py): the per-workgroup planes of a Boruvka round fold under the
+    kernel's total order (weight, min original index, max original index); the planes of the split nearest-sample search fold to
+    the first minimum.  Random planes with many ties against plain Python scans."""
+    from iggt_official_amd import _C
+
+    g = torch.Generator().manual_seed(3)
+    G, M = 5, 400
+    idx = torch.randperm(M, generator=g).int()
+    w2 = torch.randint(0, 4, (G, M), generator=g).float()                 # few distinct weights: ties everywhere
+    bp = torch.randint(0, M, (G, M), generator=g).int()
+    dead = torch.rand(G, M, generator=g) < 0.3
+    w2[dead] = float("inf")
+    bp[dead] = -1
+    w2[:, 7] = float("inf"); bp[:, 7] = -1                                # a position no plane found anything for
+    w, p = _C.fold_foreign_planes(w2, bp, idx)
+    for i in range(M):
+        cands = [(float(w2[s, i]), min(int(idx[i]), int(idx[bp[s, i]])), max(int(idx[i]), int(idx[bp[s, i]])), int(bp[s, i]))
+                 for s in range(G) if bp[s, i] >= 0]
+        if not cands:
+            assert float(w[i]) == float("inf") and int(p[i]) == -1
+            continue
+        best = min(cands)
+        assert float(w[i]) == best[0]
+        j = int(p[i])
+        assert (min(int(idx[i]), int(idx[j])), max(int(idx[i]), int(idx[j]))) == best[1:3]
+    one_w, one_p = _C.fold_foreign_planes(w2[:1], bp[:1], idx)
+    assert torch.equal(one_w, w2[0]) and torch.equal(one_p, bp[0])
+
+    S, Mq, chunk = 6, 300, 50
+    d2 = torch.randint(0, 3, (S, Mq), generator=g).float()
+    bi = (torch.arange(S)[:, None] * chunk + torch.randint(0, chunk, (S, Mq), generator=g)).int()   # plane s: rows of range s
+    empty = torch.rand(S, Mq, generator=g) < 0.2
+    d2[empty] = float("inf")
+    bi[empty] = -1
+    d2[:, 11] = float("inf"); bi[:, 11] = -1
+    got = _C.fold_nn1_planes(d2, bi)
+    for i in range(Mq):
+        cands = [(float(d2[s, i]), int(bi[s, i])) for s in range(S) if bi[s, i] >= 0]
+        assert int(got[i]) == (min(cands)[1] if cands else -1)
