@@ -92,3 +92,17 @@ def test_product_does_not_import_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M):
                         bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_attention_dispatcher_tile_choices(lib):
+    """Which instantiation the attention dispatcher picks per shape (host logic of csrc/attention.hip, no GPU needed; 256 CUs
+    assumed without a device): 256-row tiles with 128-key macro tiles for deep grids -- the global attention, and since round 3 the
+    frame / DINOv2 attention of 32 views although its 1 374-token sequences pad 12 % -- 128-row tiles for the few-view frame
+    attention, key ranges + combine for the per-rank global attention of an 8-GPU run."""
+    lab = lambda B, Nq, Nk, sb: _C.attn_kernel_label(B, 16, Nq, Nk, "f16", static_bound=sb, with_part_ws=True)
+    assert "QB=2,KVM=2" in lab(1, 43968, 43968, True) and "static-bound" in lab(1, 43968, 43968, True)
+    assert "QB=2,KVM=2" in lab(32, 1374, 1374, True) and "QB=2,KVM=2" in lab(32, 1370, 1370, False)
+    assert "QB=1,KVM=1" in lab(4, 1374, 1374, True) and "QB=1,KVM=1" in lab(8, 1374, 1374, False)
+    per_rank = lab(1, 5496, 43968, True)
+    assert "key ranges" in per_rank and "attn_combine_kernel" in per_rank
+    assert "online-max" in lab(1, 5496, 43968, False)
