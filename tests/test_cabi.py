@@ -99,6 +99,8 @@ def test_attention_dispatcher_tile_choices(lib):
     assumed without a device): 256-row tiles with 128-key macro tiles for deep grids -- the global attention, and since round 3 the
     frame / DINOv2 attention of 32 views although its 1 374-token sequences pad 12 % -- 128-row tiles for the few-view frame
     attention, key ranges + combine for the per-rank global attention of an 8-GPU run."""
+    from iggt_official_amd import _C
+
     lab = lambda B, Nq, Nk, sb: _C.attn_kernel_label(B, 16, Nq, Nk, "f16", static_bound=sb, with_part_ws=True)
     assert "QB=2,KVM=2" in lab(1, 43968, 43968, True) and "static-bound" in lab(1, 43968, 43968, True)
     assert "QB=2,KVM=2" in lab(32, 1374, 1374, True) and "QB=2,KVM=2" in lab(32, 1370, 1370, False)
