@@ -65,5 +65,11 @@ def pos_embed_rows(C: int, h: int, w: int, W: int, H: int, device, ratio: float 
     key = ("rows", C, h, w, W, H, str(device), ratio)
     if key not in _CACHE:
         xp, yp = pos_embed_xy(C, h, w, W, H, device, ratio)
-        _CACHE[key] = (xp[0, :, 0, :].t().contiguous(), yp[0, :, :, 0].t().contiguous())
+        rows = (xp[0, :, 0, :].t().contiguous(), yp[0, :, :, 0].t().contiguous())
+        # the two transposes above are kernels on the CURRENT stream; the cache is read from other streams too (the depth and
+        # point heads run side by side, models/vggt.py): an entry must be complete when it becomes visible.  (The other entries
+        # are host tensors copied synchronously.)  Never reached under graph capture: the eager warm-up run fills the cache.
+        if xp.is_cuda and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(xp.device).synchronize()
+        _CACHE[key] = rows
     return _CACHE[key]

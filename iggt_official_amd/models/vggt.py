@@ -45,12 +45,18 @@ from .aggregator import Aggregator
 
 
 _CAMERA_STREAM = os.environ.get("IGGT_CAMERA_STREAM", "1") != "0"
+# depth head beside the point head on a second side stream (see _Base._fork_head): "auto" = from 16 local views @ 518^2 worth of
+# pixels on (measured: 32 views 344.6 -> 343.0 ms; 4 local views of an 8-GPU run 60.4 -> 61.3 ms, so not there), 0 / 1 = never / always
+_HEAD_STREAMS = os.environ.get("IGGT_HEAD_STREAMS", "auto")
+_HEAD_STREAMS_MIN_PIXELS = 16 * 500 * 500
 
 
 class _Base(nn.Module, PyTorchModelHubMixin):
     def _init_runtime(self):
         self._cam_stream = None
         self._cam_pending = False
+        self._head_stream = None
+        self._head_pending = False
         self._graphs_on = False
         self._gcache = GraphCache()
         # packed weights are rebuilt when parameters change; captured graphs hold pointers to the old packs
@@ -181,6 +187,34 @@ class _Base(nn.Module, PyTorchModelHubMixin):
             torch.cuda.current_stream().wait_stream(self._cam_stream)
             self._cam_pending = False
 
+    def _fork_head(self, head, tokens_list, images, psi):
+        """Run `head` (the depth head) on a SECOND side stream while the caller goes on with the point head on its own.  The two
+        DPT heads share nothing but their read-only inputs (per-head weight packs and workspaces; split-K / compensation scratch
+        is per stream; the position tables are complete when they enter their cache), and a large part of a head is small maps --
+        19^2 ... 74^2 at 4 local views is a few dozen workgroups per launch -- that leave most of the chip idle on their own.
+        `_join_heads` makes the caller's stream wait before the outputs are handed out.  Captured like the camera head's stream
+        (fork / join inside the graph).  Worth 0.5 % at 32 views; at 4 local views it LOSES 1.5 % (the launches are too short to
+        gain from sharing the chip), hence the size rule.  IGGT_HEAD_STREAMS=0 / 1: never / always."""
+        pixels = images.shape[-4] * images.shape[-2] * images.shape[-1]
+        if _HEAD_STREAMS == "0" or (_HEAD_STREAMS != "1" and pixels < _HEAD_STREAMS_MIN_PIXELS):
+            return head(tokens_list, images=images, patch_start_idx=psi)
+        main = torch.cuda.current_stream()
+        if self._head_stream is None or self._head_stream.device != main.device:
+            self._head_stream = torch.cuda.Stream(device=main.device)
+        self._head_stream.wait_stream(main)
+        with torch.cuda.stream(self._head_stream):
+            out = head(tokens_list, images=images, patch_start_idx=psi)
+        self._head_pending = True
+        for t in out:
+            if torch.is_tensor(t):
+                t.record_stream(main)                              # allocated on the side stream, consumed on the caller's
+        return out
+
+    def _join_heads(self):
+        if self._head_pending:
+            torch.cuda.current_stream().wait_stream(self._head_stream)
+            self._head_pending = False
+
 
 class VGGT(_Base):
     def __init__(self, img_size=518, patch_size=14, embed_dim=1024, only_train_adaptor=False):
@@ -197,9 +231,10 @@ class VGGT(_Base):
     def _run(self, images, query_points=None):
         tokens, psi = self.aggregator(images)
         pred = {"pose_enc": self._camera(tokens)}
-        pred["depth"], pred["depth_conf"] = self.depth_head(tokens, images=images, patch_start_idx=psi)
+        pred["depth"], pred["depth_conf"] = self._fork_head(self.depth_head, tokens, images, psi)
         pred["world_points"], pred["world_points_conf"] = self.point_head(tokens, images=images, patch_start_idx=psi)
         self._track(pred, tokens, images, psi, query_points)
+        self._join_heads()
         self._join_camera()
         pred["images"] = images
         return pred
@@ -236,7 +271,7 @@ class IGGT(_Base):
         part_ok = (H % 28 == 0) and (W % 28 == 0)
         tokens, psi = self.aggregator(images)
         pred = {"pose_enc": self._camera(tokens)}
-        pred["depth"], pred["depth_conf"] = self.depth_head(tokens, images=images, patch_start_idx=psi)
+        pred["depth"], pred["depth_conf"] = self._fork_head(self.depth_head, tokens, images, psi)
         pts, conf, point_feat = self.point_head(tokens, images=images, patch_start_idx=psi)
         pred["world_points"], pred["world_points_conf"] = pts, conf
         if part_ok:
@@ -244,6 +279,7 @@ class IGGT(_Base):
             pred["part_feat"] = self.part_head(list(pyramid.values()), point_feature=point_feat, images=images,
                                                patch_start_idx=psi)
         self._track(pred, tokens, images, psi, query_points)
+        self._join_heads()
         self._join_camera()
         pred["images"] = images
         return pred

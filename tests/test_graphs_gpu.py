@@ -117,3 +117,37 @@ def test_batched_scenes_with_graphs():
         assert torch.equal(both["pose_enc"][-1][1], e1["pose_enc"][-1][0])
     finally:
         model.enable_graphs(False)
+
+
+def test_depth_head_on_a_side_stream_changes_nothing():
+    """models/vggt.py runs the depth head beside the point head on a second side stream for large inputs (IGGT_HEAD_STREAMS, size
+    rule).  Forced on at a small shape: outputs bit-identical to the in-line order, eagerly (repeated: a race would not be) and as a
+    captured graph (fork / join inside the capture)."""
+    from iggt_official_amd.models import vggt as mv
+    from oracle import weights
+
+    g = load_golden("demo_s3_336x504_stress")
+    m = g["meta"]
+    model = build_gpu_model(m["mode"], m["weight_seed"])
+    img = weights.make_images(m["S"], m["H"], m["W"], seed=m["image_seed"], device="cuda")
+    keys = ("depth", "depth_conf", "world_points", "world_points_conf", "part_feat")
+    old = mv._HEAD_STREAMS
+    try:
+        mv._HEAD_STREAMS = "0"
+        ref = {k: model(img)[k].clone() for k in keys}
+        mv._HEAD_STREAMS = "1"
+        for _ in range(4):
+            out = model(img)
+            torch.cuda.synchronize()
+            for k in keys:
+                assert torch.equal(out[k], ref[k]), k
+        assert model._head_stream is not None
+        model.enable_graphs(True)
+        for _ in range(3):
+            out = model(img)
+            torch.cuda.synchronize()
+            for k in keys:
+                assert torch.equal(out[k], ref[k]), ("graph", k)
+    finally:
+        mv._HEAD_STREAMS = old
+        model.enable_graphs(False)
