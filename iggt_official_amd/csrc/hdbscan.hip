@@ -13,11 +13,15 @@
 // in LDS, candidate-major, so that every lane reads the same candidate with one or two 16-byte broadcast reads (a first version
 // read it channel by channel: 8 LDS instructions per pair beside 8 FMAs).  Bound: vector ALU -- 3 C + 6 operations per pair, no
 // reuse to exploit beyond the LDS tile; M = 1.35 M points (8 views x 504 x 336) is 1.8e12 pairs per pass.
-//   * core distances keep the k smallest squared distances of a query in LDS as a max-heap, node-major ([k][256]: lane t owns
-//     column t); a candidate below the root replaces it and sifts down (log2 k steps).  (First version: unsorted slots, rescanned
-//     on every replacement -- 5.9 s of the 6.5 s the pass took at k = 100 and 1.35 M points, against 0.6 s at k = 5.)
+//   * core distances keep the k smallest squared distances of a query in LDS as a max-heap, node-major ([k][QT]: lane t owns
+//     column t; QT = 256 queries per workgroup, 128 for k > 48); a candidate below the root replaces it and sifts down (log2 k
+//     steps).  (First version: unsorted slots, rescanned on every replacement -- 5.9 s of the 6.5 s the pass took at k = 100 and
+//     1.35 M points, against 0.6 s at k = 5.)
 //   * nearest foreign: points arrive SORTED BY COMPONENT; a tile whose 256 points all belong to the component of every query of
-//     the workgroup is skipped, so that once a giant component has formed a round costs ~2 |giant| |rest| pairs instead of M^2.
+//     the workgroup is skipped, so that once a giant component has formed a round costs ~2 |giant| |rest| pairs instead of M^2;
+//     workgroups inside one component share the component's best weight so far (atomic minimum) and drop what is strictly worse;
+//     every block of 512 queries is searched by up to 32 workgroups over interleaved tiles (load balance: one outlier query used to
+//     drag its workgroup through nearly every tile while the chip idled).
 //   * both: the points are ordered along a Morton curve over their first three principal axes and every 256-point tile carries its
 //     bounding box; tiles are visited outward from the query tile and one whose box lies farther away than every query's current
 //     bound is skipped after a block-wide vote -- exact (the box gap is a lower bound of every pair distance), and what turns
