@@ -45,10 +45,11 @@ from .aggregator import Aggregator
 
 
 _CAMERA_STREAM = os.environ.get("IGGT_CAMERA_STREAM", "1") != "0"
-# depth head beside the point head on a second side stream (see _Base._fork_head): "auto" = from 16 local views @ 518^2 worth of
-# pixels on (measured: 32 views 344.6 -> 343.0 ms; 4 local views of an 8-GPU run 60.4 -> 61.3 ms, so not there), 0 / 1 = never / always
+# depth head beside the point head on a second side stream (see _Base._fork_head): "auto" = from 8 local views @ 518^2 worth of
+# pixels on (measured, profiles/r03_head_streams_ab.txt: 8 views 64.7 -> 63.7 ms, 16 views 141.1 -> 139.4, 32 views 344.6 -> 343.0;
+# 4 local views of an 8-GPU run 60.4 -> 61.3 ms, so not there), 0 / 1 = never / always
 _HEAD_STREAMS = os.environ.get("IGGT_HEAD_STREAMS", "auto")
-_HEAD_STREAMS_MIN_PIXELS = 16 * 500 * 500
+_HEAD_STREAMS_MIN_PIXELS = 8 * 500 * 500
 
 
 class _Base(nn.Module, PyTorchModelHubMixin):
@@ -193,8 +194,8 @@ class _Base(nn.Module, PyTorchModelHubMixin):
         is per stream; the position tables are complete when they enter their cache), and a large part of a head is small maps --
         19^2 ... 74^2 at 4 local views is a few dozen workgroups per launch -- that leave most of the chip idle on their own.
         `_join_heads` makes the caller's stream wait before the outputs are handed out.  Captured like the camera head's stream
-        (fork / join inside the graph).  Worth 0.5 % at 32 views; at 4 local views it LOSES 1.5 % (the launches are too short to
-        gain from sharing the chip), hence the size rule.  IGGT_HEAD_STREAMS=0 / 1: never / always."""
+        (fork / join inside the graph).  Worth 1.5 % at 8 views, 1.2 % at 16, 0.5 % at 32; at the 4 local views of an 8-GPU run it LOSES 1.5 %
+        (the launches are too short to gain from sharing the chip), hence the size rule.  IGGT_HEAD_STREAMS=0 / 1: never / always."""
         pixels = images.shape[-4] * images.shape[-2] * images.shape[-1]
         if _HEAD_STREAMS == "0" or (_HEAD_STREAMS != "1" and pixels < _HEAD_STREAMS_MIN_PIXELS):
             return head(tokens_list, images=images, patch_start_idx=psi)
