@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -34,10 +34,13 @@ _SIGNATURES = {
                                 _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
                                 _c_float, _c_int, _c_void_p],
     "iggt_flash_attn_static_bf16_d64": [_c_void_p] * 4 + [_c_int] * 4 + [_c_long] * 8
-                                      + [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_void_p],
+                                      + [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p]
+                                      + [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_void_p],
     "iggt_flash_attn_static_f16_d64": [_c_void_p] * 4 + [_c_int] * 4 + [_c_long] * 8
-                                      + [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_void_p],
+                                      + [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p]
+                                      + [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_void_p],
     "iggt_flash_attn_static_ws_bytes": [_c_int, _c_int, _c_int, _c_int],
+    "iggt_flash_attn_static_est_ws_bytes": [_c_int, _c_int, _c_int, _c_int],
     "iggt_flash_attn_static_ksplit": [_c_int, _c_int, _c_int, _c_int],
     "iggt_flash_attn_static_partial_bf16_d64": [_c_void_p] * 3 + [_c_int] * 4 + [_c_long] * 6
                                               + [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p, _c_int] + [_c_void_p] * 3,
@@ -126,7 +129,7 @@ _SIGNATURES = {
 }
 
 
-_LONG_RETURN = {"iggt_flash_attn_static_ws_bytes", "iggt_linear_f32_ws_bytes"}
+_LONG_RETURN = {"iggt_flash_attn_static_ws_bytes", "iggt_flash_attn_static_est_ws_bytes", "iggt_linear_f32_ws_bytes"}
 
 
 class HipExtensionError(RuntimeError):
@@ -235,34 +238,66 @@ LOG2E = 1.4426950408889634
 QKMAX_NUMEL = 32 + 32 * 4096   # iggt_qknorm_rope_*: 32 per-head norm maxima + scratch for the per-block partial maxima
 
 
+GUARD_WORDS = 8
+
+
 def new_attn_guard(device):
-    """Persistent adaptive-switch state of one static-bound attention call site (include/iggt_hip.h): int32 [4] =
-    {state (-1: never measured), flagged tiles of the last launch (-1: static kernel skipped), tiles, calls}."""
-    return torch.tensor([-1, 0, 0, 0], dtype=torch.int32, device=device)
+    """Persistent adaptive-switch state of one static-bound attention call site (include/iggt_hip.h): int32 [8] =
+    {state (-1: never measured), redone work items of the last launch (-1: static kernel skipped), work items, calls,
+     mode of the static kernel (0: norm bound, 1: estimated shift), rows redone one by one (-1: skipped), 0, 0}."""
+    return torch.tensor([-1, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=device)
 
 
 def _guard_ok(g):
-    assert g is None or (g.dtype == torch.int32 and g.numel() >= 4 and g.is_contiguous() and g.is_cuda)
+    assert g is None or (g.dtype == torch.int32 and g.numel() >= GUARD_WORDS and g.is_contiguous() and g.is_cuda)
 
 
 def flash_attn_d64_static(q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, qkmax, flags,
-                          q_rows_per_wg=0, part_ws=None, guard=None, guard_prev=None):
+                          q_rows_per_wg=0, part_ws=None, guard=None, guard_prev=None, est_ws=None, key_period=0,
+                          key_nspecial=0, est_mode=0):
     """Static-bound attention (include/iggt_hip.h): q carries scale * log2(e), qkmax fp32 [>= 32]: entries 16..31 = per-head
     norm bound of k as written by qknorm_rope(..., q_scale, qkmax) or k_rownorm_max; flags int32 scratch; part_ws: optional
     byte scratch (static_attn_ws_bytes) that lets small grids split the keys into ranges; guard / guard_prev: new_attn_guard
-    tensors of this call site / of the same launch one layer earlier (None: always try the static kernel)."""
-    _dev(q, k, v, o, qkmax, flags, part_ws, guard, guard_prev)
+    tensors of this call site / of the same launch one layer earlier (None: always try the static kernel); est_ws: optional
+    byte scratch (static_attn_est_ws_bytes) that turns on the row-granular hand-over and the estimated-shift mode, whose key
+    sample includes the first key_nspecial keys of every key_period keys; est_mode: the mode when guard is None."""
+    _dev(q, k, v, o, qkmax, flags, part_ws, guard, guard_prev, est_ws)
     sfx = _h16(q, k, v, o)
     assert qkmax.dtype == torch.float32 and qkmax.numel() >= 32 and qkmax.is_contiguous()
     assert flags.dtype == torch.int32 and flags.is_contiguous()
     assert part_ws is None or (part_ws.dtype == torch.uint8 and part_ws.is_contiguous())
+    assert est_ws is None or (est_ws.dtype == torch.uint8 and est_ws.is_contiguous())
     _guard_ok(guard), _guard_ok(guard_prev)
     fn = getattr(load(), f"iggt_flash_attn_static_{sfx}_d64")
     rc = fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, Nq, Nk,
             q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, qkmax.data_ptr(), flags.data_ptr(), flags.numel(),
-            _ptr(part_ws), 0 if part_ws is None else part_ws.numel(), q_rows_per_wg, _ptr(guard), _ptr(guard_prev), _stream())
+            _ptr(part_ws), 0 if part_ws is None else part_ws.numel(), q_rows_per_wg, _ptr(guard), _ptr(guard_prev),
+            _ptr(est_ws), 0 if est_ws is None else est_ws.numel(), int(key_period), int(key_nspecial), int(est_mode), _stream())
     _check(rc, f"iggt_flash_attn_static_{sfx}_d64")
     return o
+
+
+def static_attn_est_ws_bytes(B, H, Nq, Nk):
+    """Bytes of scratch for flash_attn_d64_static(..., est_ws=...) at this shape."""
+    return int(load().iggt_flash_attn_static_est_ws_bytes(B, H, Nq, Nk))
+
+
+EST_HI_CAP = 1024   # csrc/attention_common.h
+
+
+def static_attn_est_views(est_ws, B, H, Nq):
+    """Typed views into an est_ws buffer (csrc/attention_common.h est_view; reports, tests and probes): rowshift fp32 [BH, Nq],
+    rowlist int32 [BH, Nq], rowcount int32 [BH], hicount int32 [BH], hilist int32 [BH, EST_HI_CAP], rowflag uint8 [BH, NqP]."""
+    BH, NqP = B * H, (Nq + 15) // 16 * 16
+    o1 = BH * Nq * 4
+    o2 = o1 + BH * Nq * 4
+    o3 = o2 + BH * 4
+    o4 = o3 + BH * 4
+    o5 = (o4 + BH * EST_HI_CAP * 4 + 15) // 16 * 16
+    return dict(rowshift=est_ws[:o1].view(torch.float32).view(BH, Nq), rowlist=est_ws[o1:o2].view(torch.int32).view(BH, Nq),
+                rowcount=est_ws[o2:o3].view(torch.int32), hicount=est_ws[o3:o4].view(torch.int32),
+                hilist=est_ws[o4:o4 + BH * EST_HI_CAP * 4].view(torch.int32).view(BH, EST_HI_CAP),
+                rowflag=est_ws[o5:o5 + BH * NqP].view(BH, NqP))
 
 
 def static_attn_ws_bytes(B, H, Nq, Nk):

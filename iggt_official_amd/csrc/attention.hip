@@ -65,6 +65,7 @@ int fill_params(AttnParams& p, const void* q, const void* k, const void* v, void
     p.scale_log2 = 1.f; p.qtiles = 0; p.qkmax = nullptr; p.flags = nullptr; p.static_min_l = 0.f;
     p.ksplit = 0; p.slot0 = 0; p.seg_len = 0; p.skip_seg = -1; p.seg_kmax = nullptr; p.o_part = nullptr; p.l_part = nullptr; p.c_part = nullptr;
     p.guard = nullptr; p.guard_prev = nullptr; p.guard_retry = GUARD_RETRY_DEFAULT;
+    p.est_ws = nullptr; p.est_force = 0;
     return 0;
 }
 
@@ -167,7 +168,8 @@ static int flash_attn_static_combine_h16(int fmt, const void* o_part, const floa
 static int flash_attn_static_h16(int fmt, const void* q, const void* k, const void* v, void* o, int B, int H, int Nq,
                                  int Nk, long q_bs, long q_rs, long k_bs, long k_rs, long v_bs, long v_rs, long o_bs,
                                  long o_rs, const float* qkmax, int* flags, int flags_len, void* part_ws, long part_ws_len,
-                                 int q_rows_per_wg, int* guard, const int* guard_prev, void* stream) {
+                                 int q_rows_per_wg, int* guard, const int* guard_prev, void* est_ws, long est_ws_len,
+                                 int key_period, int key_nspecial, int est_mode, void* stream) {
     AttnParams p;
     const int rc = fill_params(p, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs);
     if (rc) return rc;
@@ -194,8 +196,21 @@ static int flash_attn_static_h16(int fmt, const void* q, const void* k, const vo
     if (e != hipSuccess) return (int)e;
     p.qkmax = qkmax; p.flags = flags; p.guard = guard; p.guard_prev = guard_prev;
     p.static_min_l = fmt == FMT_F16 ? STATIC_MIN_L_PER_KEY_F16 * (float)Nk : STATIC_MIN_L_BF16;
+    const bool est = est_ws != nullptr;
+    if (est) {   // row-granular hand-over + (adaptive, or est_mode = 1 without a guard) the estimated shift
+        if (est_ws_len < est_ws_size(B, H, Nq) || ((uintptr_t)est_ws % 16)) return -8;
+        p.est_ws = (unsigned char*)est_ws;
+        p.est_force = est_mode ? 1 : 0;
+        const int r = iggt_launch_attn_est_prepass(p, key_period, key_nspecial, fmt, (hipStream_t)stream);
+        if (r) return r;
+        IGGT_CHECK_LAUNCH();
+    }
     iggt_launch_flash_attn_v3(p, rows, code / 1000 - 4, fmt, true, (hipStream_t)stream);
     IGGT_CHECK_LAUNCH();
+    if (est) {
+        iggt_launch_attn_rowlist(p, (hipStream_t)stream);
+        IGGT_CHECK_LAUNCH();
+    }
     p.qkmax = nullptr;   // gated dynamic pass: q already carries scale * log2 e
     iggt_launch_flash_attn_v3(p, rows, code / 1000 - 4, fmt, false, (hipStream_t)stream);
     IGGT_CHECK_LAUNCH();
@@ -222,9 +237,11 @@ extern "C" int iggt_flash_attn_static_bf16_d64(const void* q, const void* k, con
                                    int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
                                    long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
                                    int* flags, int flags_len, void* part_ws, long part_ws_bytes_len, int q_rows_per_wg,
-                                   int* guard, const int* guard_prev, void* stream) {
+                                   int* guard, const int* guard_prev, void* est_ws, long est_ws_len, int key_period,
+                                   int key_nspecial, int est_mode, void* stream) {
     return flash_attn_static_h16(FMT_BF16, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
-                                 qkmax, flags, flags_len, part_ws, part_ws_bytes_len, q_rows_per_wg, guard, guard_prev, stream);
+                                 qkmax, flags, flags_len, part_ws, part_ws_bytes_len, q_rows_per_wg, guard, guard_prev,
+                                 est_ws, est_ws_len, key_period, key_nspecial, est_mode, stream);
 }
 
 extern "C" int iggt_flash_attn_static_partial_bf16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq,
@@ -251,9 +268,11 @@ extern "C" int iggt_flash_attn_static_f16_d64(const void* q, const void* k, cons
                                    int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
                                    long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
                                    int* flags, int flags_len, void* part_ws, long part_ws_bytes_len, int q_rows_per_wg,
-                                   int* guard, const int* guard_prev, void* stream) {
+                                   int* guard, const int* guard_prev, void* est_ws, long est_ws_len, int key_period,
+                                   int key_nspecial, int est_mode, void* stream) {
     return flash_attn_static_h16(FMT_F16, q, k, v, o, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
-                                 qkmax, flags, flags_len, part_ws, part_ws_bytes_len, q_rows_per_wg, guard, guard_prev, stream);
+                                 qkmax, flags, flags_len, part_ws, part_ws_bytes_len, q_rows_per_wg, guard, guard_prev,
+                                 est_ws, est_ws_len, key_period, key_nspecial, est_mode, stream);
 }
 
 extern "C" int iggt_flash_attn_static_partial_f16_d64(const void* q, const void* k, const void* v, int B, int H, int Nq,
@@ -298,6 +317,12 @@ extern "C" int iggt_flash_attn_d64_kernel_name(int B, int H, int Nq, int Nk, int
 extern "C" int iggt_flash_attn_static_ksplit(int B, int H, int Nq, int Nk) {
     const int ks = choose_ksplit(B, H, Nq, Nk);
     return ks > 1 ? ks : 1;
+}
+
+/* bytes of the estimated-shift / row-granular workspace of iggt_flash_attn_static_* for this shape */
+extern "C" long iggt_flash_attn_static_est_ws_bytes(int B, int H, int Nq, int Nk) {
+    (void)Nk;
+    return est_ws_size(B, H, Nq);
 }
 
 /* bytes of partial workspace iggt_flash_attn_static_* needs to be allowed to split the keys of this shape (0: never splits) */

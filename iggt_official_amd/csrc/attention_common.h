@@ -41,17 +41,72 @@ struct AttnParams {
     // guard_prev (the same kind of block one layer earlier).  The gated online-max pass updates the word from the number of
     // flagged tiles (attention_v3.hip guard_update): more than 1/8 flagged -> the next guard_retry calls skip the static
     // kernel.  guard[1] / [2] / [3] = flagged tiles / tiles / calls of the last launch (reports).  nullptr: always static.
+    //   guard[4] = mode of the static kernel (round 4): 0 = Cauchy-Schwarz bound from the norms; 1 = ESTIMATED shift (below);
+    //   guard[5] = query rows the last launch handed to the online-max pass one by one (-1: static kernel skipped).
     int* guard;
     const int* guard_prev;
     int guard_retry;
+    // Round 4 -- estimated-shift static softmax + row-granular redo (attention_est.hip; one-pass launches only).
+    //   rowshift [B*H][Nq] fp32: per query row min(Cauchy-Schwarz bound, sampled row maximum + est_slack), written by the
+    //     pre-pass (attn_rowshift_kernel) over a key sample = special tokens + strided keys + keys of outlying norm;
+    //   rowflag  [B*H][NqP] bytes: 1 = the static kernel does not vouch for this row (row sum below the acceptance threshold,
+    //     or a non-finite accumulator: an fp16 numerator overflowed because the row's true maximum lies more than the
+    //     headroom above the sampled one);
+    //   rowlist  [B*H][Nq] int32 / rowcount [B*H]: the flagged rows of each (batch, head) in ascending order
+    //     (attn_rowlist_kernel) -- the online-max pass recomputes exactly those rows, 128 * QB per workgroup.
+    // The six arrays live in ONE caller-owned buffer (est_ws; the kernels derive the sub-arrays from B, H, Nq -- est_view below:
+    // six more pointers in the argument block cost the static kernel 4 scalar registers it does not have, and the spill that
+    // followed put a 16-byte reload into its tile loop).  nullptr: round-3 behaviour (norm bound, whole tiles flagged).
+    unsigned char* est_ws;
+    int est_force;    // guard == nullptr: 1 = estimated shift, 0 = norm bound
 };
+constexpr int EST_HI_CAP = 1024;   // keys of outlying norm kept per (batch, head); more than that is not an outlier set
+// layout of est_ws: rowshift fp32 [BH][Nq] | rowlist int32 [BH][Nq] | rowcount int32 [BH] | hicount int32 [BH] |
+//                   hilist int32 [BH][EST_HI_CAP] | (16-byte aligned) rowflag bytes [BH][NqP],  NqP = Nq rounded up to 16
+struct EstView {
+    float* rowshift;
+    int* rowlist;
+    int* rowcount;
+    int* hicount;
+    int* hilist;
+    unsigned char* rowflag;
+    int NqP;
+};
+__host__ __device__ inline long est_off_rowflag(long BH, long Nq) {
+    return (BH * Nq * 8 + BH * 8 + BH * EST_HI_CAP * 4 + 15) / 16 * 16;
+}
+__host__ __device__ inline long est_ws_size(int B, int H, int Nq) {
+    const long BH = (long)B * H;
+    return est_off_rowflag(BH, Nq) + BH * ((Nq + 15) / 16 * 16);
+}
+__host__ __device__ inline EstView est_view(const AttnParams& p) {
+    const long BH = (long)p.B * p.H, Nq = p.Nq;
+    EstView v;
+    v.rowshift = reinterpret_cast<float*>(p.est_ws);
+    v.rowlist = reinterpret_cast<int*>(p.est_ws + BH * Nq * 4);
+    v.rowcount = reinterpret_cast<int*>(p.est_ws + BH * Nq * 8);
+    v.hicount = v.rowcount + BH;
+    v.hilist = v.hicount + BH;
+    v.rowflag = p.est_ws + est_off_rowflag(BH, Nq);
+    v.NqP = (int)((Nq + 15) / 16 * 16);
+    return v;
+}
 constexpr int GUARD_RETRY_DEFAULT = 16;
+constexpr int GUARD_WORDS = 8;
 // resolve the guard word(s) to "skip the static-bound kernel in this call"
 IGGT_DEVINL bool guard_skips(const int* guard, const int* guard_prev) {
     if (guard == nullptr) return false;
     int g = guard[0];
     if (g < 0) g = (guard_prev != nullptr && guard_prev[0] > 0) ? 1 : 0;
     return g > 0;
+}
+// ... and to the mode the static kernel runs in (0: norm bound, 1: estimated shift); a call site that has never been measured
+// inherits the mode of the same kind of launch one layer earlier
+IGGT_DEVINL int guard_mode(const AttnParams& p) {
+    if (p.est_ws == nullptr) return 0;
+    if (p.guard == nullptr) return p.est_force;
+    if (p.guard[0] < 0) return p.guard_prev != nullptr ? p.guard_prev[4] : 0;
+    return p.guard[4];
 }
 
 constexpr int KV_TILE = 64;
@@ -89,9 +144,21 @@ constexpr float STATIC_SHIFT_F16 = 15.0f;
 constexpr float STATIC_MIN_L_PER_KEY_F16 = 1.0f / 8192.0f;
 constexpr float STATIC_MIN_L_BF16 = 1e-30f;
 
+// estimated-shift mode: headroom (log2 units) between the sampled row maximum and the top of the fp16 range; the sampled
+// maximum itself lands on 2^(STATIC_SHIFT_F16 - slack), which must stay above the acceptance threshold Nk * 2^-13 (host side)
+inline float est_slack_for(int Nk) {
+    int lg = 0;
+    while ((1L << lg) < (long)Nk) ++lg;                  // ceil(log2 Nk)
+    const int s = (int)STATIC_SHIFT_F16 - (lg - 13) - 1;
+    return (float)(s > 12 ? 12 : (s < 4 ? 4 : s));
+}
+
 }  // namespace iggt_attn
 
 // experimental variants live in their own translation units
 int iggt_launch_flash_attn_v3(const iggt_attn::AttnParams& p, int q_rows, int kvm, int fmt, bool static_bound,
                               hipStream_t stream);
 int iggt_launch_attn_combine(const iggt_attn::AttnParams& p, int nslots, int q_rows, int fmt, hipStream_t stream);
+// attention_est.hip: key scan (outlying norms), row-shift pre-pass, flagged-row compaction
+int iggt_launch_attn_est_prepass(const iggt_attn::AttnParams& p, int key_period, int key_nspecial, int fmt, hipStream_t stream);
+int iggt_launch_attn_rowlist(const iggt_attn::AttnParams& p, hipStream_t stream);

@@ -64,25 +64,49 @@ constexpr bool PIN_DEFAULT = true;
 // Adaptive switch, evaluated by workgroup 0 of the gated online-max pass (it runs right behind the static-bound kernel or
 // the combine kernel on the same stream, so the flags are final and nobody reads the guard word any more in this call):
 // count the flagged tiles and decide what the NEXT call of this block does (attention_common.h AttnParams::guard).
-IGGT_DEVINL void guard_update(const AttnParams& p, int nwork, char* smem) {
-    int n = 0;
+IGGT_DEVINL void guard_update(const AttnParams& p, int nwork, int rows_per_item, char* smem) {
+    int n = 0, nrows = 0;
     for (int i = threadIdx.x; i < nwork; i += 256) n += p.flags[i] != 0;
+    if (p.est_ws != nullptr) {   // rows handed over one by one (estimated-shift / row-granular launches): in work items
+        const int* rowcount = est_view(p).rowcount;
+        for (int i = threadIdx.x; i < p.B * p.H; i += 256) {
+            const int c = rowcount[i];
+            nrows += c;
+            n += (c + rows_per_item - 1) / rows_per_item;
+        }
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    for (int o = 32; o > 0; o >>= 1) {
+        n += __shfl_xor(n, o, 64);
+        nrows += __shfl_xor(nrows, o, 64);
+    }
     int* red = reinterpret_cast<int*>(smem);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n;
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = n;
+        red[4 + (threadIdx.x >> 6)] = nrows;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         n = red[0] + red[1] + red[2] + red[3];
+        nrows = red[4] + red[5] + red[6] + red[7];
         const int g0 = p.guard[0];
         const bool skipped = guard_skips(p.guard, p.guard_prev);
+        int mode = guard_mode(p);
         int g;
-        if (skipped) g = (g0 < 0 ? p.guard_retry : g0) - 1;           // this call ran the online-max kernel only: count down
-        else g = ((long)n * 8 > (long)nwork) ? p.guard_retry : 0;     // > 1/8 of the tiles flagged: static + redo loses
+        if (skipped) {
+            g = (g0 < 0 ? p.guard_retry : g0) - 1;                    // this call ran the online-max kernel only: count down
+        } else if ((long)n * 8 > (long)nwork) {                       // > 1/8 of the work redone: static + redo loses
+            if (mode == 0 && p.est_ws != nullptr) { mode = 1; g = 0; }   // the norm bound is loose here: estimate the shift
+            else g = p.guard_retry;                                   // nothing static helps: online-max only for a while
+        } else {
+            g = 0;
+        }
         p.guard[0] = g;
         p.guard[1] = skipped ? -1 : n;
         p.guard[2] = nwork;
         p.guard[3] = p.guard[3] + 1;
+        p.guard[4] = mode;
+        p.guard[5] = skipped ? -1 : nrows;
     }
     __syncthreads();   // smem is reused by the K / V staging below
 }
@@ -93,7 +117,13 @@ IGGT_DEVINL void guard_update(const AttnParams& p, int nwork, char* smem) {
 // grids: the per-rank global attention of an 8-GPU run has 352 256-row tiles for 512 workgroup slots; four key ranges make
 // 1 408 quarter-length workgroups (0.75 instead of 1.0 tile-times), and (b) to start on a rank's own keys while the K/V
 // all-gather of the other ranks is still in flight (iggt_official_amd/dist.py).
-template <int QB, int KVM, int FMT, bool STATIC, bool PIN = PIN_DEFAULT, bool PART = false>
+// EST (static bound, one pass only; round 4): the shift of every query row comes from the pre-pass table (attention_est.hip) instead
+// of the norms, rows are handed to the online-max pass one by one (rowflag) instead of as 256-row tiles, and a non-finite
+// accumulator (an fp16 numerator above the range) marks a row like a row sum below the threshold does.  A separate
+// instantiation on purpose: the norm-bound kernel sits at the 256-register limit, and the same code with both paths behind a
+// run-time switch put a 16-byte spill reload into its tile loop (8-11 spilled registers instead of 2 outside the loop).  Both
+// instantiations are launched; each returns at once unless the adaptive-switch word names its mode.
+template <int QB, int KVM, int FMT, bool STATIC, bool PIN = PIN_DEFAULT, bool PART = false, bool EST = false>
 __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KVM * BUF_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -101,19 +131,33 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     const int frow = lane & 31, fhalf = lane >> 5;
 
     const int work = xcd_remap(blockIdx.x, gridDim.x);
+    // online-max pass in LIST mode (round 4): the work item recomputes rows [qt * 128 QB, ...) of the (batch, head)'s list of
+    // flagged rows (attention_est.hip attn_rowlist_kernel) instead of a contiguous query tile
+    int nlist = -1;
+    const int* rlist = nullptr;
     if constexpr (!STATIC) {
-        // fallback pass behind the static-bound kernel: only the flagged query tiles are recomputed
+        // fallback pass behind the static-bound kernel: only the flagged query tiles / rows are recomputed
         if (p.flags != nullptr) {
-            if (p.guard != nullptr && blockIdx.x == 0) guard_update(p, (int)gridDim.x, smem);
-            if (p.flags[work] == 0) return;
+            if (p.guard != nullptr && blockIdx.x == 0) guard_update(p, (int)gridDim.x, 128 * QB, smem);
+            if (p.flags[work] == 0) {
+                if (p.est_ws == nullptr) return;
+                const EstView ev = est_view(p);
+                const int bh_ = work / p.qtiles;
+                nlist = ev.rowcount[bh_];
+                if ((work % p.qtiles) * (128 * QB) >= nlist) return;
+                rlist = ev.rowlist + (long)bh_ * p.Nq;
+            }
         }
     } else {
         // adaptive switch: a block whose tiles kept failing the acceptance test goes straight to the online-max kernel
         if (guard_skips(p.guard, p.guard_prev)) {
-            if constexpr (!PART) {
+            if constexpr (!PART && !EST) {
                 if (tid == 0) p.flags[work] = 1;
             }
             return;
+        }
+        if constexpr (!PART) {
+            if ((guard_mode(p) == 1) != EST) return;   // the other instantiation's turn
         }
     }
     const int qt = work % p.qtiles;
@@ -141,6 +185,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     for (int qb = 0; qb < QB; ++qb) {
         int qr = q_base + qb * 32 + frow;
         qr = qr < p.Nq ? qr : p.Nq - 1;
+        if constexpr (!STATIC) {
+            if (rlist != nullptr) qr = rlist[q_base + qb * 32 + frow < nlist ? q_base + qb * 32 + frow : nlist - 1];
+        }
         const bf16_t* src = qb_ptr + (long)qr * p.q_rs + 8 * fhalf;
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) qf[qb][kc] = *reinterpret_cast<const bf16x8*>(src + 16 * kc);
@@ -212,24 +259,36 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         // vector -- a second one would cost 16 more VGPRs in a kernel that sits at the 256-register limit of two waves per
         // SIMD -- so the lane uses the larger of its two norms.  Rows with a small |q^| (most rows, when a few outlier tokens
         // dominate max_i |q^_i|) no longer inherit the outliers' shift.
-        float n2 = 0.f;
+        float shift;
+        if constexpr (EST) {   // min(norm bound, sampled row maximum + headroom) per row, from the pre-pass
+            const float* rs = reinterpret_cast<const float*>(p.est_ws) + (long)bh * p.Nq;
+            shift = -INFINITY;
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            float a2 = 0.f;
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                const u32x4 w = __builtin_bit_cast(u32x4, qf[qb][kc]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float lo = h2_lo<FMT>(w[e]), hi = h2_hi<FMT>(w[e]);
-                    a2 += lo * lo + hi * hi;
-                }
+            for (int qb = 0; qb < QB; ++qb) {
+                const int qr = q_base + qb * 32 + frow;
+                shift = fmaxf(shift, rs[qr < p.Nq ? qr : p.Nq - 1]);
             }
-            a2 += __shfl_xor(a2, 32, 64);
-            n2 = fmaxf(n2, a2);
+            shift -= (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
+        } else {
+            float n2 = 0.f;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float a2 = 0.f;
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const u32x4 w = __builtin_bit_cast(u32x4, qf[qb][kc]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = h2_lo<FMT>(w[e]), hi = h2_hi<FMT>(w[e]);
+                        a2 += lo * lo + hi * hi;
+                    }
+                }
+                a2 += __shfl_xor(a2, 32, 64);
+                n2 = fmaxf(n2, a2);
+            }
+            const float kmax = (PART && p.seg_kmax != nullptr) ? p.seg_kmax[ks * 32 + 16 + h] : p.qkmax[16 + h];
+            shift = sqrtf(n2) * kmax * 1.00002f + 1e-3f - (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
         }
-        const float kmax = (PART && p.seg_kmax != nullptr) ? p.seg_kmax[ks * 32 + 16 + h] : p.qkmax[16 + h];
-        const float shift = sqrtf(n2) * kmax * 1.00002f + 1e-3f - (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
 #pragma unroll
         for (int r = 0; r < 16; ++r) cinit[r] = -shift;
     } else {
@@ -395,11 +454,36 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     bool weak = false;   // static bound only: some row's numerators sank towards the subnormal range
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const int qr = q_base + qb * 32 + frow;
+        int qr = q_base + qb * 32 + frow;
         const float l = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
         const float inv = (PART && !(l > 0.f)) ? 0.f : 1.0f / l;
-        if constexpr (STATIC && !PART) weak = weak || (qr < p.Nq && !(l >= p.static_min_l));
-        if (qr < p.Nq) {
+        if constexpr (STATIC && !PART) {
+            bool bad = !(l >= p.static_min_l);
+            if constexpr (EST) {   // an fp16 numerator above the range rounds to +inf: the accumulator is then inf or NaN
+                float chk = 0.f;
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) chk = __builtin_fmaf(o[qb][dh][r], 0.f, chk);
+                chk += __shfl_xor(chk, 32, 64);
+                bad = bad || !(chk == 0.f);
+            }
+            if constexpr (EST) {   // row-granular hand-over
+                const long npad = (p.Nq + 15) / 16 * 16;
+                if (fhalf == 0 && qr < p.Nq)
+                    (p.est_ws + est_off_rowflag((long)p.B * p.H, p.Nq))[(long)bh * npad + qr] = bad ? 1 : 0;
+            } else {
+                weak = weak || (qr < p.Nq && bad);
+            }
+        }
+        bool live = qr < p.Nq;
+        if constexpr (!STATIC) {
+            if (rlist != nullptr) {
+                live = qr < nlist;
+                qr = rlist[live ? qr : nlist - 1];
+            }
+        }
+        if (live) {
             bf16_t* dst = ob_ptr + (long)qr * p.o_rs + 4 * fhalf;
             if constexpr (PART) {   // partial slot (slot0 + ks): dense [slot][B][Nq][H * 64] rows, l as [slot][B][H][Nq]
                 const long slot = p.slot0 + ks - ((p.seg_len > 0 && p.skip_seg >= 0 && ks > p.skip_seg) ? 1 : 0);
@@ -469,20 +553,20 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnParams p, i
 }  // namespace
 
 // Launched from the dispatcher in attention.hip: q_rows = 256 | 128 query rows per workgroup, kvm = 64-key tiles per macro tile.
-template <int FMT, bool STATIC, bool PART>
+template <int FMT, bool STATIC, bool PART, bool EST = false>
 static void launch_v3(const AttnParams& p_in, int q_rows, int kvm, hipStream_t stream) {
     AttnParams p = p_in;
     const int mult = PART ? p.ksplit : 1;
     if (q_rows == 256) {
         p.qtiles = (p.Nq + 255) / 256;
         const dim3 grid(p.B * p.H * p.qtiles * mult), block(256);
-        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2, FMT, STATIC, PIN_DEFAULT, PART>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 1, FMT, STATIC, PIN_DEFAULT, PART>), grid, block, 0, stream, p);
+        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2, FMT, STATIC, PIN_DEFAULT, PART, EST>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 1, FMT, STATIC, PIN_DEFAULT, PART, EST>), grid, block, 0, stream, p);
     } else {
         p.qtiles = (p.Nq + 127) / 128;
         const dim3 grid(p.B * p.H * p.qtiles * mult), block(256);
-        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 2, FMT, STATIC, PIN_DEFAULT, PART>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 1, FMT, STATIC, PIN_DEFAULT, PART>), grid, block, 0, stream, p);
+        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 2, FMT, STATIC, PIN_DEFAULT, PART, EST>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 1, FMT, STATIC, PIN_DEFAULT, PART, EST>), grid, block, 0, stream, p);
     }
 }
 
@@ -493,6 +577,10 @@ int iggt_launch_flash_attn_v3(const AttnParams& p, int q_rows, int kvm, int fmt,
     } else if (static_bound) {
         if (fmt == FMT_F16) launch_v3<FMT_F16, true, false>(p, q_rows, kvm, stream);
         else launch_v3<FMT_BF16, true, false>(p, q_rows, kvm, stream);
+        if (p.est_ws != nullptr) {   // the estimated-shift instantiation: runs when the adaptive switch names mode 1
+            if (fmt == FMT_F16) launch_v3<FMT_F16, true, false, true>(p, q_rows, kvm, stream);
+            else launch_v3<FMT_BF16, true, false, true>(p, q_rows, kvm, stream);
+        }
     } else {
         if (fmt == FMT_F16) launch_v3<FMT_F16, false, false>(p, q_rows, kvm, stream);
         else launch_v3<FMT_BF16, false, false>(p, q_rows, kvm, stream);

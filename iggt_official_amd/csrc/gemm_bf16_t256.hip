@@ -54,11 +54,34 @@ IGGT_DEVINL void wait_vmcnt() {
 // between the MFMAs.  Measured at M=43968, N=1024, K=4096 (TF/s): lockstep kernel 745; ping-pong 789 / 799 / 799 for
 // placement 0 / 1 / 2; L2-hot source 962; no DMA 1258; no fragment reads 808 -> the LDS-DMA path (issue + LDS write
 // ~24 %, L2-miss latency ~18 %) is what separates this kernel from the matrix pipe, not the LDS reads.
-template <int MODE, int DBG, int FMT>
+//
+// Round 4 -- GELU from an LDS table (template parameter LUT; fc1 only).  Counters on the shipping fc1 kernel
+// (profiles/r03_gemm_pmc.txt) showed 7.0 vector instructions per MFMA, 5 of them the erf-GELU of the epilogue (1 v_rcp +
+// 1 v_exp + ~12 FMA-class operations per element, the two transcendentals at quarter rate), ~19 us of a 46 us tile round with
+// the matrix pipe idle.  The LDS pipe is idle in that phase (1 LDS instruction per MFMA over the kernel), and 32 KiB of the
+// CU's 160 KiB are unused beside the 128 KiB ring: every workgroup builds, before its K loop, a 2 048-interval table of
+// Phi(x) = (1 + erf(x / sqrt 2)) / 2 over [-8, 8) as (value, forward difference) pairs -- 4 entries per thread through the
+// exact erff, no memory traffic -- and the epilogue evaluates gelu(x) = x (f_i + frac * d_i): fma, med3, floor, sub, cvt,
+// ds_read_b64, fma, mul per element.  |error| <= 2.5e-6 absolute (1e-4 of the value in the negative tail, where fp16's own
+// rounding is 4.9e-4), tests/test_kernels_f16_gpu.py gates it against torch's erf GELU at the kernel tolerance.
+constexpr int LUT_N = 2048;
+constexpr float LUT_SCALE = 128.f, LUT_OFF = 1024.f;
+constexpr int LUT_BYTES = (LUT_N + 1) * 8;
+
+IGGT_DEVINL float gelu_lut(float x, const float2* lut) {
+    float t = fmaf(x, LUT_SCALE, LUT_OFF);
+    t = __builtin_amdgcn_fmed3f(t, 0.f, 2047.996f);   // x <= -8: Phi = 6e-16; x >= 8: Phi = 1 to fp32
+    const float fi = floorf(t);
+    const float2 e = lut[(int)fi];
+    return x * fmaf(t - fi, e.y, e.x);
+}
+
+template <int MODE, int DBG, int FMT, bool LUT = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_t256pp_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2* lut = reinterpret_cast<float2*>(smem + NSTAGE * STAGE_BYTES);   // behind the ring (LUT builds only)
     const int wm = wave >> 2, wn = wave & 3;
     const int v = xcd_remap(blockIdx.x, gridDim.x);
     // Tile order inside an XCD's contiguous chunk: groups of group_m row-tiles, m fastest inside a group, so the ~32
@@ -157,6 +180,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256pp_kernel(const GemmPara
     dma_half(1, 0);
     dma_half(1, 1);
     dma_half(2, 0);
+    if constexpr (LUT) {   // while the first stages are in flight: 4 table entries per thread (+ the guard entry)
+        float f[5];
+#pragma unroll
+        for (int e = 0; e < 5; ++e) {
+            const float x = (float)(tid * 4 + e - (int)LUT_OFF) * (1.0f / LUT_SCALE);
+            f[e] = 0.5f + 0.5f * erff(x * 0.70710678118654752440f);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lut[tid * 4 + e] = make_float2(f[e], f[e + 1] - f[e]);
+        if (tid == 0) lut[LUT_N] = make_float2(1.0f, 0.0f);
+    }
     wait_vmcnt<6>();
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();  // the wm = 1 waves run one barrier behind
@@ -249,7 +283,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256pp_kernel(const GemmPara
                 // the 32 passes of a tile then cost a memory round trip, 5 of the 12 us this epilogue took (qkv 662 -> 736 TF/s)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v4[e] += bias4[e];
-                if (p.act == 1) {
+                if constexpr (LUT) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = gelu_lut(v4[e], lut);
+                } else if (p.act == 1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v4[e] = gelu_erf(v4[e]);
                 } else if (p.act == 2) {
@@ -275,6 +312,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256pp_kernel(const GemmPara
 template <int FMT>
 static int launch_t256(const GemmParams& p, int mode, int tiles_m, hipStream_t stream) {
     const int lds = NSTAGE * STAGE_BYTES;  // 128 KiB
+    static int gelu_lut_on = -1;           // IGGT_GELU_LUT=0: the polynomial erfc epilogue (gemm_common.h gelu_erf)
+    if (gelu_lut_on < 0) {
+        const char* e = getenv("IGGT_GELU_LUT");
+        gelu_lut_on = (e && atoi(e) == 0) ? 0 : 1;
+    }
     // Production: DMA placement 2 (DBG = 16).  IGGT_GEMM_PPDBG=<bits> (mode-2 GEMMs only) selects an ablation:
     // 1 no DMA in the loop, 4 L2-hot DMA source, 0 / 8 DMA placement 0 / 1 (profiles/r01_gemm_pmc.txt).
     static int ppdbg = -2;
@@ -294,6 +336,9 @@ static int launch_t256(const GemmParams& p, int mode, int tiles_m, hipStream_t s
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return (int)e;
         }
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_t256pp_kernel<1, 16, FMT, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds + LUT_BYTES);
+        if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const dim3 grid(tiles_m * p.tiles_n), block(512);
@@ -309,7 +354,9 @@ static int launch_t256(const GemmParams& p, int mode, int tiles_m, hipStream_t s
         else hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<2, 0, FMT>), grid, block, lds, stream, p);
         return 0;
     }
-    if (mode == 1) hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<1, 16, FMT>), grid, block, lds, stream, p);
+    if (mode == 1 && p.act == 1 && gelu_lut_on)
+        hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<1, 16, FMT, true>), grid, block, lds + LUT_BYTES, stream, p);
+    else if (mode == 1) hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<1, 16, FMT>), grid, block, lds, stream, p);
     else if (mode == 2) hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<2, 16, FMT>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((gemm_bf16_t256pp_kernel<3, 16, FMT>), grid, block, lds, stream, p);
     return 0;

@@ -270,9 +270,15 @@ class Block(nn.Module):
                     flags = ws.get("attn_flags", (batch * H * ((tokens + 127) // 128),), torch.int32, dev)
                     nws = _C.static_attn_ws_bytes(batch, H, tokens, Nk) if q_rows_per_wg == 0 else 0
                     part_ws = ws.get("attn_part", (nws,), torch.uint8, dev) if nws else None
+                    est_ws = None
+                    if guard is not None and not nws and precision.attn_estimated_shift():
+                        est_ws = ws.get("attn_est", (_C.static_attn_est_ws_bytes(batch, H, tokens, Nk),), torch.uint8, dev)
+                    # the estimated-shift pre-pass samples the special tokens of every view among the keys: the first
+                    # `patch_start` rows of every P rows (frame attention: of the one view; global: of each view)
                     _C.flash_attn_d64_static(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
                                              tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,
-                                             qkmax, flags, q_rows_per_wg, part_ws, guard, guard_prev)
+                                             qkmax, flags, q_rows_per_wg, part_ws, guard, guard_prev, est_ws=est_ws,
+                                             key_period=rope_geom["P"], key_nspecial=rope_geom["patch_start"])
                 else:
                     _C.flash_attn_d64(qkv, k_src, v_src, ao, batch, H, tokens, Nk,
                                       tokens * 3 * C, 3 * C, k_bs, kv_rs, k_bs, kv_rs, tokens * C, C,

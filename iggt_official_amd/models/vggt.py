@@ -91,6 +91,7 @@ class _Base(nn.Module, PyTorchModelHubMixin):
         # everything that selects WHICH kernels / collectives get captured is part of the key
         key = (tuple(images.shape), precision.operand_name(), precision.static_softmax(),
                precision.mean_compensation_sites(), precision.gather_overlap(), precision.debug_saturation(), precision.static_guard(),
+               precision.attn_estimated_shift(),
                convops.PREC, convops.DPT_PREC,
                None if shard is None else (shard.rank, shard.world, shard.kv_groups, shard.force))
 
@@ -169,7 +170,10 @@ class _Base(nn.Module, PyTorchModelHubMixin):
         cam = None
         if shard is not None and shard.active:
             local = tokens_list[-1][0, :, 0]                      # [S_local, 2C]
-            cam = shard.all_gather_rows(local)[None]               # [1, S, 2C]
+            # a private copy, taken on the main stream before the fork: the gathered rows live in the shard's reusable
+            # `rows_out` buffer, which the track head's feature-map gather (main stream) rewrites -- and on its first call
+            # reallocates -- while the camera head may still be reading it on the side stream
+            cam = shard.all_gather_rows(local)[None].clone()       # [1, S, 2C]
         if not _CAMERA_STREAM:
             return self.camera_head(tokens_list, camera_tokens=cam)
         main = torch.cuda.current_stream()

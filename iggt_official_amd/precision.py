@@ -108,6 +108,23 @@ def set_static_guard(on: bool) -> None:
     _static_guard = bool(on)
 
 
+# Estimated-shift mode of the static-bound attention + row-granular hand-over to the online-max pass (csrc/attention_est.hip,
+# round 4): where the norm bound is loose (trained-like q/k-norm affines, sink keys, register tokens of outlying norm) the
+# adaptive switch moves a call site to a shift estimated from each row's exact maximum over a key sample instead of giving the
+# call to the online-max kernel.  One-pass launches only (single GPU and the gather-first form).  IGGT_ATTN_EST=0: round-3
+# behaviour (norm bound, whole 256-row tiles flagged); needs the adaptive switch (IGGT_STATIC_GUARD).
+_attn_est = os.environ.get("IGGT_ATTN_EST", "1") != "0"
+
+
+def attn_estimated_shift() -> bool:
+    return _attn_est and _static_guard and _static_softmax
+
+
+def set_attn_estimated_shift(on: bool) -> None:
+    global _attn_est
+    _attn_est = bool(on)
+
+
 # Multi-GPU: hide the K/V all-gather behind the attention over a rank's own keys (layers/blocks.py _attend_overlapped; needs
 # the static softmax).  IGGT_GATHER_OVERLAP=0 restores gather -> one attention launch.
 _gather_overlap = os.environ.get("IGGT_GATHER_OVERLAP", "1") != "0"

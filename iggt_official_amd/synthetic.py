@@ -13,8 +13,17 @@ Modes
              backbone, i.e. the reference's init scales (aggregator.py:63,153).
   "stress" : gamma ~ U(0.5, 1.5) everywhere, so that an error in any attention / MLP kernel
              reaches the outputs un-attenuated.
+  "trained_like": "stress" plus the statistics in which a trained DINOv2-with-registers / VGGT-family checkpoint
+             departs from bounded-uniform draws (round-3 review, item 1b): log-normal (sigma = 1) scales on every
+             q_norm / k_norm / norm1 / norm2 weight (reference attention.py:43-44,54: learned affines), GAUSSIAN Linear /
+             Conv weights with ~0.1 % of the input columns at 8x, and camera / register tokens at 30x the norm of a
+             patch token (reference aggregator.py:123-124: attention-sink / high-norm tokens).  The draws go through
+             Python-built fp32 tables (inverse normal CDF, exp) indexed by the integer hash, so they stay bit-identical
+             between CPU and GPU -- no device transcendental is involved.
 All other tensors are drawn so that activations stay O(1) through the network.
 """
+import math
+import statistics
 import zlib
 
 import torch
@@ -42,6 +51,61 @@ def hash_uniform(n: int, key: int, device="cpu") -> torch.Tensor:
 
 _SQRT12 = 12.0 ** 0.5
 
+# --- trained_like: table-driven Gaussian / log-normal draws (bit-identical on every device) --------------------------------
+_NQ = 4096                 # inverse-CDF knots: z_k = Phi^-1((k + 0.5) / _NQ), |z| <= 3.66
+_TABLES = {}
+
+
+def _tables(device):
+    key = str(device)
+    if key not in _TABLES:
+        nd = statistics.NormalDist()
+        z = [nd.inv_cdf((k + 0.5) / _NQ) for k in range(_NQ)]
+        zt = torch.tensor(z + [z[-1]], dtype=torch.float32)                    # one guard knot for the interpolation
+        _TABLES[key] = zt.to(device)
+    return _TABLES[key]
+
+
+def hash_normal(n: int, key: int, device="cpu") -> torch.Tensor:
+    """n reproducible ~N(0,1) fp32 samples: the hash's 24 bits pick a knot of the inverse normal CDF (upper 12 bits) and
+    interpolate linearly to the next one (lower 12 bits); exact fp32 multiply-adds on table values only."""
+    zt = _tables(device)
+    u = hash_uniform(n, key, device) * float(_NQ)          # exact: k / 2**24 * 2**12
+    idx = u.floor()
+    frac = u - idx                                           # exact
+    idx = idx.to(torch.int64)
+    lo, hi = zt[idx], zt[idx + 1]
+    return lo + frac * (hi - lo)
+
+
+def hash_lognormal(n: int, key: int, device="cpu", sigma: float = 1.0) -> torch.Tensor:
+    """n reproducible exp(sigma * N(0,1)) fp32 samples (exponent knots quantised to 1/16; range e^(+-3.7 sigma))."""
+    tkey = (str(device), float(sigma))
+    if tkey not in _TABLES:
+        nd = statistics.NormalDist()
+        _TABLES[tkey] = torch.tensor([math.exp(round(sigma * nd.inv_cdf((k + 0.5) / _NQ) * 16.0) / 16.0)
+                                      for k in range(_NQ)], dtype=torch.float32).to(device)
+    idx = (hash_uniform(n, key, device) * float(_NQ)).floor().to(torch.int64)
+    return _TABLES[tkey][idx]
+
+
+# "trained_like" takes its knobs from the mode string itself, so that a fixture's meta["mode"] names them all:
+#   trained_like                      = the defaults below
+#   trained_like(qk=0.5,tok=10)       = overrides
+_TL_DEFAULTS = dict(qk=1.0, norm=1.0, tok=30.0, col=8.0, colfrac=1e-3, gauss=1.0)
+
+
+def trained_like_options(mode: str) -> dict:
+    o = dict(_TL_DEFAULTS)
+    if "(" in mode:
+        body = mode[mode.index("(") + 1:mode.rindex(")")]
+        for item in filter(None, (t.strip() for t in body.split(","))):
+            k, v = item.split("=")
+            if k not in o:
+                raise ValueError(f"unknown trained_like option {k!r}")
+            o[k] = float(v)
+    return o
+
 
 def make_tensor(name: str, shape, seed: int, mode: str, device="cpu") -> torch.Tensor:
     """Synthetic value of state-dict entry `name`.  All draws are uniform (centred draws are scaled
@@ -62,6 +126,34 @@ def make_tensor(name: str, shape, seed: int, mode: str, device="cpu") -> torch.T
     def one_plus(std):
         return ((hash_uniform(n, key, device) - 0.5) * (_SQRT12 * std) + 1.0).view(shape)
 
+    heavy = mode.startswith("trained_like")
+    if heavy:
+        o = trained_like_options(mode)
+        if leaf == "weight" and len(shape) == 1:
+            parent = name.split(".")[-2]
+            sig = o["qk"] if parent in ("q_norm", "k_norm") else o["norm"] if parent in ("norm1", "norm2") else 0.0
+            if sig > 0.0:
+                return hash_lognormal(n, key, device, sig).view(shape)
+        if leaf in ("camera_token", "register_token") and o["tok"] > 0.0:
+            return (hash_normal(n, key, device) * o["tok"]).view(shape)
+        if leaf == "weight" and len(shape) >= 2 and not name.endswith("updateformer.flow_head.weight") and o["gauss"]:
+            conv_t = ".resize_layers." in name and len(shape) == 4 and _is_conv_transpose(name)
+            if conv_t:
+                fan = shape[0] * (4 if shape[2] == 4 and "part_adaptor" in name else 1)
+            else:
+                fan = 1
+                for s_ in shape[1:]:
+                    fan *= s_
+            w = (hash_normal(n, key, device) * (fan ** -0.5)).view(shape)
+            if o["col"] > 1.0:
+                # ~0.1 % of the INPUT columns (dim 1 of [out, in, ...]; dim 0 of a ConvTranspose2d's [in, out, kh, kw])
+                cdim = 0 if conv_t else 1
+                pick = hash_uniform(shape[cdim], _name_seed(name + "#outlier", seed), device) < o["colfrac"]
+                view = [1] * len(shape)
+                view[cdim] = shape[cdim]
+                w = w * torch.where(pick, o["col"], 1.0).to(torch.float32).view(view)
+            return w
+        mode = "stress"          # everything else: as in "stress"
     if leaf == "gamma":  # LayerScale
         if mode == "stress":
             return uniform(0.5, 1.5)

@@ -66,23 +66,39 @@ int iggt_flash_attn_f16_d64(const void* q, const void* k, const void* v, void* o
  * entries, zeroed here) and are recomputed by the online-max kernel in the same call, so the result meets the tolerance of
  * iggt_flash_attn_* for ANY input.  part_ws (NULL or part_ws_len >= iggt_flash_attn_static_ws_bytes(..) bytes of scratch)
  * lets a grid too small for the chip split the keys into ranges whose partial results are folded by a second kernel.
- * guard (NULL or int[4], persistent per call site, initialised to {-1, 0, 0, 0}) makes the launch adaptive: the gated
+ * guard (NULL or int[8], persistent per call site, initialised to {-1, 0, ...}) makes the launch adaptive: the gated
  * online-max pass counts the flagged tiles and, when more than 1/8 were flagged, lets the next 16 calls skip the static
  * kernel (flag every tile at once) before it is tried again; a call site that has never been measured (guard[0] < 0)
  * inherits the verdict of guard_prev (NULL or the guard of the same kind of launch one layer earlier).  guard[1..3] =
  * flagged tiles (-1: skipped) / tiles / calls of the last launch.  Worst case of a launch: ~1.05x the online-max kernel
- * averaged over calls instead of static + online-max.  Same reference operation. */
+ * averaged over calls instead of static + online-max.  Same reference operation.
+ * ABI 23 (round 4): guard is int[8], initialised to {-1, 0, 0, 0, 0, 0, 0, 0}; guard[4] = mode of the static kernel (0: norm
+ * bound, 1: estimated shift), guard[5] = rows handed to the online-max pass one by one (-1: skipped).
+ * est_ws (NULL: the behaviour above; else est_ws_len >= iggt_flash_attn_static_est_ws_bytes(..) bytes of 16-byte aligned
+ * scratch) turns on, for one-pass launches, (a) the ROW-granular hand-over -- the static kernel marks single rows, a small
+ * kernel compacts them into ascending lists per (batch, head) and the online-max pass recomputes exactly those rows, 128 or
+ * 256 per workgroup -- and (b) the ESTIMATED shift (csrc/attention_est.hip): where the norm bound is loose (trained-like
+ * q/k-norm affines, sink keys, register tokens of outlying norm: more than 1/8 of the work redone under mode 0) the guard
+ * switches the call site to mode 1, in which a pre-pass takes every row's exact maximum over a key sample -- the first
+ * key_nspecial keys of every key_period keys (the special tokens of each view; 0: none), ~Nk / 32 strided keys, and the keys
+ * whose norm exceeds half the head's maximum -- and the static kernel shifts row i by min(norm bound, sampled maximum +
+ * headroom).  A row whose true maximum lies beyond the headroom overflows to a non-finite accumulator and is recomputed like
+ * any other marked row.  More than 1/8 of the work redone in mode 1 as well -> online-max only for 16 calls, as before.
+ * est_mode: the mode when guard is NULL (0 / 1); ignored otherwise. */
 int iggt_flash_attn_static_bf16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
                                     int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
                                     long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
                                     int* flags, int flags_len, void* part_ws, long part_ws_len, int q_rows_per_wg,
-                                    int* guard, const int* guard_prev, void* stream);
+                                    int* guard, const int* guard_prev, void* est_ws, long est_ws_len, int key_period,
+                                    int key_nspecial, int est_mode, void* stream);
 int iggt_flash_attn_static_f16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
                                    int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
                                    long v_bs, long v_rs, long o_bs, long o_rs, const float* qkmax,
                                    int* flags, int flags_len, void* part_ws, long part_ws_len, int q_rows_per_wg,
-                                   int* guard, const int* guard_prev, void* stream);
+                                   int* guard, const int* guard_prev, void* est_ws, long est_ws_len, int key_period,
+                                   int key_nspecial, int est_mode, void* stream);
 long iggt_flash_attn_static_ws_bytes(int B, int H, int Nq, int Nk);
+long iggt_flash_attn_static_est_ws_bytes(int B, int H, int Nq, int Nk);
 /* number of key ranges iggt_flash_attn_static_* would cut this shape into when given a workspace (1: one pass) */
 int iggt_flash_attn_static_ksplit(int B, int H, int Nq, int Nk);
 

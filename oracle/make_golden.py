@@ -42,6 +42,17 @@ CASES = {
     "full_s32_518_stress": (32, 518, 518, "stress", 0, 8, 11, 97, 4),
     # BASELINE.json configs[4]'s per-view shape: 1036^2 (74 x 74 patch grid, 5 481 tokens per view; part head valid)
     "full_s2_1036_stress": (2, 1036, 1036, "stress", 0, 9, 14, 64, 4),
+    # round 4 (review item 1b): weight statistics in which a trained checkpoint departs from bounded-uniform draws
+    # (iggt_official_amd/synthetic.py "trained_like": log-normal q/k-norm and norm1/norm2 scales, Gaussian weights with 8x
+    # outlier columns, camera / register tokens at 30x), at BASELINE.json configs[1]'s size.  Three doses:
+    #   tlA  sigma 0.5 / 0.5: the heaviest tails at which the reference's OWN bf16 autocast mode still tracks its fp32 path to
+    #        < 1e-2 (probes/trained_like_sweep.py) -- gated at north_star's 1e-3 like every other fixture;
+    #   tlB  sigma 0.75 (q/k) / 0.5: past that edge; reported, gated loosely;
+    #   tlC  the review's literal recipe, sigma 1 / 1: global-attention logits of std 15 (near-argmax softmax); the reference's
+    #        fp32 arithmetic itself sits 8e-4 from an fp64 evaluation and its bf16 mode is 0.56 off -- reported, not gated.
+    "full_s8_518_tlA": (8, 518, 518, "trained_like(qk=0.5,norm=0.5)", 0, 7, 7, 32, 4),
+    "full_s8_518_tlB": (8, 518, 518, "trained_like(qk=0.75,norm=0.5)", 0, 7, 7, 32, 4),
+    "full_s8_518_tlC": (8, 518, 518, "trained_like", 0, 7, 7, 32, 4),
 }
 # BASELINE.json configs[0]: REAL photographs (the reference's iggt_demo scenes, copied to tests/golden/images/ as data
 # fixtures) through the reference's OWN loader (iggt/utils/load_fn.py, torchvision.transforms.ToTensor stubbed): every other
@@ -52,9 +63,12 @@ REAL = {
     "real_demo7_s4_crop518_stress": ("demo7", "crop", None, "stress", 0, 7, 16, 2),      # 4 x 518 x 518, geometry
     "real_demo1_s3_336x504_stress": ("demo1", "resize", (504, 336), "stress", 0, 7, 16, 2),   # demo.py:59,182-186 default size
     "real_demo7_s4_336x504_stress": ("demo7", "resize", (504, 336), "stress", 0, 7, 16, 2),
+    "real_demo7_s4_crop518_tlA": ("demo7", "crop", None, "trained_like(qk=0.5,norm=0.5)", 0, 7, 16, 2),
+    "real_demo7_s4_crop518_tlC": ("demo7", "crop", None, "trained_like", 0, 7, 16, 2),
 }
 IMAGE_DIR = os.path.join(GOLDEN_DIR, "images")
-LARGE = ("full_s8_518_stress", "full_s32_518_stress", "full_s2_1036_stress") + tuple(REAL)
+LARGE = ("full_s8_518_stress", "full_s32_518_stress", "full_s2_1036_stress", "full_s8_518_tlA", "full_s8_518_tlB",
+         "full_s8_518_tlC") + tuple(REAL)
 # The reference's part head evaluates `cross_attention_1` (whose result it discards, part_head.py:178-185) with an explicit
 # softmax over (4g)^2 x (4g)^2 scores per frame and head: 87 616^2 x 8 x 4 B = 245 GB at 1036^2 -- it cannot run here.
 NO_PART = ("full_s2_1036_stress",)
@@ -241,7 +255,7 @@ def main():
     ints = {k: v.clone() for k, v in model.state_dict().items() if not v.dtype.is_floating_point and v.numel() > 1}
     torch.save(ints, os.path.join(OUT_DIR, "int_buffers.pt"))
     if argv == ["real"]:
-        argv = list(REAL)
+        argv = [n for n in REAL if n.endswith("_stress")]
     names = argv or [c for c in CASES if c not in LARGE]
     for n in names:
         run_case(model, n)

@@ -6,7 +6,8 @@ hidden activation are rounded to a 16-bit format, everything else (accumulation,
 statistics, residual stream) stays fp32 -- and reports the relative l2 error of the aggregated tokens against
 plain fp32 for bf16 (8 significant bits) and fp16 (11 bits).
 
-    python -m oracle.precision_sim [S] [H] [W] [--ablate]     (--ablate: leave one rounding site at a time in fp32)
+    python -m oracle.precision_sim [S] [H] [W] [--ablate] [--mode=stress|default|trained_like ...]
+    (--ablate: leave one rounding site at a time in fp32)
 """
 import sys
 
@@ -69,7 +70,8 @@ def main():
     S, H, W = (int(a) for a in (args[:3] + ["2", "56", "56"][len(args):]))
     import json, os
     schema = json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "state_dict_schema.json")))
-    for mode in ("stress", "default"):
+    modes = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--mode=")] or ["stress", "default"]
+    for mode in modes:
         sd = weights.fill_state_dict(schema, seed=1, mode=mode, device="cpu")
         sd = {k: v for k, v in sd.items() if k.startswith("aggregator.")}
         images = weights.make_images(S, H, W, seed=2, device="cpu")
@@ -80,7 +82,7 @@ def main():
                 errs = {i: float((out[i] - ref[i]).norm() / ref[i].norm()) for i in ref}
                 print(f"weights={mode:8s} operands={fmt}: token l2 error per kept layer "
                       + " ".join(f"{i}:{e:.2e}" for i, e in errs.items()), flush=True)
-            if mode == "stress" and "--ablate" in sys.argv:
+            if mode != "default" and "--ablate" in sys.argv:
                 for name in SITES + ("w_qkv", "w_proj", "w_fc1", "w_fc2"):
                     out = run(sd, images, "fp16", exact=(name,))
                     e = float((out[23] - ref[23]).norm() / ref[23].norm())

@@ -1,0 +1,209 @@
+"""Estimated-shift static softmax + row-granular hand-over (GPU; csrc/attention_est.hip, round 4).
+
+The four score regimes of probes/attn_static_robustness.py at a test size: LayerNorm-of-noise q / k, trained-like q/k-norm
+affines (log-normal per-channel scales), sink keys of 10x the norm at random positions, register-token query rows of 30x the
+norm.  For each: the result must meet the kernel tolerance of the online-max kernel against an fp64 softmax; the pre-pass table
+must equal min(norm bound, exact maximum over the documented key sample + headroom); the rows handed to the online-max pass must
+be the ones the documentation says; and the adaptive switch must walk norm bound -> estimated shift -> online-max only."""
+import math
+
+import pytest
+import torch
+
+from conftest import report
+from test_kernels_gpu import _attn_ref, _relerr
+
+pytestmark = pytest.mark.gpu
+F16 = torch.float16
+LOG2E = 1.4426950408889634
+
+
+@pytest.fixture(scope="module")
+def C():
+    from iggt_official_amd import _C
+
+    _C.load()
+    return _C
+
+
+def _make(kind, dt, B, H, N, P, seed=3):
+    """qkv [B * N, 3 * H * 64] with q pre-scaled by scale * log2 e (x 1.3 for a realistic spread), views of P tokens whose first
+    5 rows are the special tokens."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(B * N, 3, H, 64, generator=g, device="cuda")
+    qk = x[:, :2]
+    qk = (qk - qk.mean(-1, keepdim=True)) / qk.std(-1, keepdim=True, unbiased=False)       # per-head LayerNorm: |.| = 8
+    if kind != "noise":
+        gam = torch.exp(torch.randn(2, H, 64, generator=g, device="cuda"))                  # log-normal, sigma = 1
+        gam = gam / gam.pow(2).mean(-1, keepdim=True).sqrt()
+        qk = qk * gam[None]
+    x[:, :2] = qk
+    x[:, 0] *= 0.125 * LOG2E * 1.3
+    special = (torch.arange(B * N, device="cuda") % N) % P < 5
+    if kind == "sinks":
+        idx = torch.randperm(B * N, generator=g, device="cuda")[:8 * B]
+        x[idx, 1] *= 10.0
+    if kind == "registers":
+        x[special, 0] *= 30.0
+    return x.reshape(B * N, 3 * H * 64).to(dt), special
+
+
+def _qkmax(x, B, H, N):
+    qkmax = torch.zeros(32, device="cuda")
+    qkmax[16:16 + H] = x.view(B * N, 3, H, 64)[:, 1].float().norm(dim=-1).amax(0)
+    return qkmax
+
+
+def _launch(C, qkv, B, H, N, qkmax, *, tile=0, guard=None, guard_prev=None, est=True, est_mode=1, P=0, est_ws=None):
+    Cd = H * 64
+    flags = torch.zeros(B * H * ((N + 127) // 128), dtype=torch.int32, device="cuda")
+    o = torch.full((B * N, Cd), float("nan"), dtype=qkv.dtype, device="cuda")
+    if est and est_ws is None:
+        est_ws = torch.full((C.static_attn_est_ws_bytes(B, H, N, N),), 0x5A, dtype=torch.uint8, device="cuda")   # garbage in
+    C.flash_attn_d64_static(qkv, qkv[:, Cd:], qkv[:, 2 * Cd:], o, B, H, N, N, N * 3 * Cd, 3 * Cd, N * 3 * Cd, 3 * Cd,
+                            N * 3 * Cd, 3 * Cd, N * Cd, Cd, qkmax, flags, tile, None, guard, guard_prev,
+                            est_ws=est_ws if est else None, key_period=P, key_nspecial=5 if P else 0, est_mode=est_mode)
+    torch.cuda.synchronize()
+    return o, flags, est_ws
+
+
+def _ref(qkv, B, H, N):
+    x = qkv.view(B, N, 3, H, 64)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    return _attn_ref(q, k, v, 0.6931471805599453).transpose(1, 2).reshape(B * N, H * 64)
+
+
+def _check(o, ref, dt):
+    assert not torch.isnan(o.float()).any()
+    mx, l2 = _relerr(o, ref)
+    if dt == F16:
+        assert mx < 2e-3 and l2 < 5e-4, (mx, l2)
+    else:
+        assert mx < 1.5e-2 and l2 < 4e-3, (mx, l2)
+    return mx, l2
+
+
+@pytest.mark.parametrize("dt", [F16, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["noise", "affine", "sinks", "registers"])
+@pytest.mark.parametrize("B,H,N,P,tile", [(1, 4, 6870, 1374, 6256), (3, 16, 1374, 1374, 0)])
+def test_estimated_shift_meets_the_kernel_tolerance(C, dt, kind, B, H, N, P, tile):
+    """Global-attention-like (one batch of 5 views) and frame-attention-like (3 views of 1 374 tokens, automatic tile: 128-row
+    workgroups) launches in the estimated-shift mode, every regime, both operand formats."""
+    qkv, special = _make(kind, dt, B, H, N, P)
+    qkmax = _qkmax(qkv, B, H, N)
+    o, flags, ws = _launch(C, qkv, B, H, N, qkmax, tile=tile, P=P)
+    mx, l2 = _check(o, _ref(qkv, B, H, N), dt)
+    v = C.static_attn_est_views(ws, B, H, N)
+    redone = int(v["rowcount"].sum())
+    nspecial = int(special.sum()) * H
+    report(f"attn_est/{kind}_{'f16' if dt == F16 else 'bf16'}_B{B}_H{H}_N{N}", dict(max=mx, l2=l2, rows_redone=redone,
+                                                                                 rows=B * H * N, hi_keys=v["hicount"].tolist()))
+    assert int(flags.sum()) == 0                         # no whole tile was handed over
+    if kind in ("noise", "sinks"):
+        assert redone == 0, redone
+    if kind == "sinks":                                  # the key scan found every sink, by norm alone
+        assert int(v["hicount"].sum()) >= 8 * B and int(v["hicount"].max()) <= 8 * B
+    if kind == "registers" and dt == F16:
+        # the outlying query rows cannot be bracketed by any sample: they -- and little else -- go to the online-max pass
+        assert nspecial // 2 <= redone <= nspecial + B * H * N // 100, (redone, nspecial)
+    if kind == "affine":
+        assert redone <= B * H * N // 8, redone          # heavy-tailed scores: well below what would make the switch give up
+    # every list is ascending, in range and as long as its count says
+    for bh in range(B * H):
+        n = int(v["rowcount"][bh])
+        rows = v["rowlist"][bh, :n]
+        assert n == 0 or (bool((rows[1:] > rows[:-1]).all()) and int(rows[0]) >= 0 and int(rows[-1]) < N)
+        assert int(v["rowflag"][bh, :N].ne(0).sum()) == n
+
+
+@pytest.mark.parametrize("kind", ["affine", "sinks"])
+def test_prepass_table_is_min_of_norm_bound_and_sampled_maximum(C, kind):
+    """attn_keyscan_kernel + attn_rowshift_kernel against a torch restatement of the documented sample: special tokens of
+    every view, every stride-th key, keys whose norm exceeds half the head's maximum."""
+    B, H, N, P = 1, 2, 5496, 1374
+    qkv, _ = _make(kind, F16, B, H, N, P, seed=11)
+    qkmax = _qkmax(qkv, B, H, N)
+    _, _, ws = _launch(C, qkv, B, H, N, qkmax, tile=6256, P=P)
+    v = C.static_attn_est_views(ws, B, H, N)
+    x = qkv.view(N, 3, H, 64).float()
+    target = min(max(N // 32, 128), 1024)
+    stride = max(N // target, 1)
+    slack = float(min(max(15 - (math.ceil(math.log2(N)) - 13) - 1, 4), 12))
+    for h in range(H):
+        q, k = x[:, 0, h], x[:, 1, h]
+        kn = k.norm(dim=-1)
+        hi = torch.nonzero(kn > 0.5 * qkmax[16 + h]).flatten()
+        assert int(v["hicount"][h]) == hi.numel()
+        if hi.numel() <= C.EST_HI_CAP:
+            assert sorted(v["hilist"][h, :hi.numel()].tolist()) == hi.tolist()
+        idx = torch.cat([(torch.arange(N // P, device="cuda")[:, None] * P + torch.arange(5, device="cuda")[None]).flatten(),
+                         torch.arange(0, N, stride, device="cuda"), hi if hi.numel() <= C.EST_HI_CAP else hi[:0]])
+        m = (q @ k[idx].t()).amax(dim=1)
+        cs = q.norm(dim=-1) * qkmax[16 + h] * 1.00002 + 1e-3
+        want = torch.minimum(cs, m + slack)
+        got = v["rowshift"][h]
+        assert float((got - want).abs().max()) < 2e-2, float((got - want).abs().max())
+        true_max = (q @ k.t()).amax(dim=1)
+        if kind == "sinks":      # every sink is in the sample: no numerator 2^(s - shift + 15) leaves the fp16 range
+            assert bool((got >= true_max - 1.0).all())
+
+
+def test_adaptive_switch_walks_norm_bound_estimated_online(C):
+    """guard[4] (mode) and guard[0] (skip countdown): sink keys defeat the norm bound -> the call site moves to the estimated
+    shift and stays there; an input that defeats the estimate as well (every query row with a score spread no sample brackets)
+    -> online-max only for 16 calls, then the estimated shift is tried again.  Results meet the tolerance in every state."""
+    B, H, N, P = 1, 2, 5496, 1374
+    sinks, _ = _make("sinks", F16, B, H, N, P, seed=5)
+    qm = _qkmax(sinks, B, H, N)
+    ref = _ref(sinks, B, H, N)
+    ntiles = H * ((N + 255) // 256)
+    ws = torch.zeros(C.static_attn_est_ws_bytes(B, H, N, N), dtype=torch.uint8, device="cuda")
+    guard = C.new_attn_guard("cuda")
+    o, flags, _ = _launch(C, sinks, B, H, N, qm, tile=6256, guard=guard, P=P, est_ws=ws)
+    _check(o, ref, F16)
+    st = guard.tolist()
+    assert st[4] == 1 and st[0] == 0 and st[1] > ntiles // 8 and st[3] == 1, st       # norm bound lost: estimate next time
+    assert int(flags.sum()) > ntiles // 8
+    for i in range(3):
+        o, flags, _ = _launch(C, sinks, B, H, N, qm, tile=6256, guard=guard, P=P, est_ws=ws)
+        _check(o, ref, F16)
+        st = guard.tolist()
+        assert st[4] == 1 and st[0] == 0 and 0 <= st[1] <= ntiles // 8 and int(flags.sum()) == 0, (i, st)
+    # a fresh call site behind this one inherits the mode
+    fresh = C.new_attn_guard("cuda")
+    o, flags, _ = _launch(C, sinks, B, H, N, qm, tile=6256, guard=fresh, guard_prev=guard, P=P, est_ws=ws)
+    _check(o, ref, F16)
+    assert fresh.tolist()[4] == 1 and 0 <= fresh.tolist()[1] <= ntiles // 8 and int(flags.sum()) == 0, fresh.tolist()
+    # every query row 40x: score spreads of ~100 bits, the sampled maximum is tens of bits below the true one on most rows
+    wild = sinks.clone()
+    wild.view(N, 3, H, 64)[:, 0] *= 40.0
+    qm_w, ref_w = _qkmax(wild, B, H, N), _ref(wild, B, H, N)
+    o, flags, _ = _launch(C, wild, B, H, N, qm_w, tile=6256, guard=guard, P=P, est_ws=ws)
+    _check(o, ref_w, F16)
+    st = guard.tolist()
+    assert st[4] == 1 and st[0] == 16 and st[5] > N * H // 8, st                       # the estimate lost too: online-max only
+    for i in range(16):
+        o, flags, _ = _launch(C, wild, B, H, N, qm_w, tile=6256, guard=guard, P=P, est_ws=ws)
+        st = guard.tolist()
+        assert st[0] == 15 - i and st[1] == -1 and st[5] == -1 and int(flags.sum()) == ntiles, (i, st)
+        if i in (0, 15):
+            _check(o, ref_w, F16)
+    o, flags, _ = _launch(C, wild, B, H, N, qm_w, tile=6256, guard=guard, P=P, est_ws=ws)    # tried again, in mode 1
+    _check(o, ref_w, F16)
+    assert guard.tolist()[0] == 16 and guard.tolist()[4] == 1, guard.tolist()
+
+
+def test_workspace_without_guard_keeps_the_norm_bound_kernel(C):
+    """est_mode 0 with a workspace and no guard = round-3 arithmetic (norm bound, whole tiles flagged), bit for bit; est_mode 1
+    on LayerNorm-of-noise operands hands no row over and meets the tolerance."""
+    B, H, N, P = 1, 2, 4000, 0
+    qkv, _ = _make("noise", F16, B, H, N, 1374, seed=9)
+    qm = _qkmax(qkv, B, H, N)
+    ref = _ref(qkv, B, H, N)
+    o0, flags0, _ = _launch(C, qkv, B, H, N, qm, tile=6256, est=False)
+    o1, flags1, ws = _launch(C, qkv, B, H, N, qm, tile=6256, est_mode=0)
+    assert torch.equal(o0, o1) and int(flags0.sum()) == 0 and int(flags1.sum()) == 0
+    assert int(C.static_attn_est_views(ws, B, H, N)["rowcount"].sum()) == 0
+    o2, _, ws2 = _launch(C, qkv, B, H, N, qm, tile=6256, est_mode=1)
+    _check(o2, ref, F16)
+    assert int(C.static_attn_est_views(ws2, B, H, N)["rowcount"].sum()) == 0

@@ -66,6 +66,24 @@ def test_bench_self_launches_its_ranks():
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "view-shard x2" and d["output_check"]["ok"]
 
 
+def test_bench_self_launch_eight_ranks_one_device():
+    """`python bench.py --gpus 8 --views 8` through the self-launch, all eight ranks on cuda:0 over gloo: the control flow of
+    BASELINE.json configs[3] (one view per rank here, hipGraph segments, max-over-ranks timing) with every rank's outputs
+    checked against its slice of the reference fixture and the worst rank reported."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["IGGT_BENCH_SINGLE_DEVICE"] = "1"
+    env["IGGT_BENCH_BF16_LEG"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--views", "8", "--steps", "1",
+                          "--warmup", "1"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 8 and d["graphs"] is True and d["config"]["parallelism"] == "view-shard x8"
+    assert d["output_check"]["ok"] and d["output_check"]["max_l2_all_ranks"] < 1e-3
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_gpus8_views8_single_device.json"), "w") as f:
+        json.dump(d, f)
+
+
 def test_bench_emulated_rank_line():
     """`--emulate-world W` (developer mode): one middle rank of a W-GPU run on this GPU as a bench-shaped record -- hipGraph
     segments on, per-rank attention shape in the roofline entry, no output check (the other ranks' keys are copies)."""

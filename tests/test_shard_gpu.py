@@ -56,6 +56,14 @@ def _worker(rank, world, port, case, kv_groups, graphs, overlap, ret, backend="g
         model.set_view_shard(shard)
         v0, v1 = shard.local_views(m["S"])
         images = weights.make_images(m["S"], m["H"], m["W"], seed=m["image_seed"], device="cuda")[v0:v1]
+        # which special-token slot this rank hands to its first view (reference aggregator.py:338-361: slot 0 belongs to view 0
+        # of the SCENE, i.e. to rank 0 alone) -- recorded at the one call site that writes them
+        from iggt_official_amd import _C
+        slot0_calls = []
+        orig_wst = _C.write_special_tokens
+        _C.write_special_tokens = lambda *a: (slot0_calls.append(bool(a[-1])), orig_wst(*a))[1]
+        cap = {}
+        hook = model.aggregator.register_forward_hook(lambda mod, i, o: cap.__setitem__("tokens", o[0]))
         if graphs:   # hipGraph segments with the collectives as eager steps between them (iggt_official_amd/graphs.py)
             model.enable_graphs(True)
             model(images)                       # capture
@@ -66,10 +74,26 @@ def _worker(rank, world, port, case, kv_groups, graphs, overlap, ret, backend="g
             # eager steps: per global block the K/V gather (begin + finish when it overlaps the own-key attention) + 1 camera gather
             assert seg.num_segments == (48 if overlap else 24) + 1 + 1, seg.num_segments
             model.enable_graphs(False)
+        hook.remove()
+        _C.write_special_tokens = orig_wst
         res = {}
+        ss, ts, cs = m.get("spatial_stride", 1), m.get("token_stride", 1), m.get("channel_stride", 1)
         for k in ("depth", "depth_conf", "world_points", "world_points_conf", "part_feat"):
             if k in g:
-                res[k] = errors(pred[k], g[k][:, v0:v1])[1]
+                got = pred[k][:, :, :, ::ss, ::ss] if k == "part_feat" else pred[k][:, :, ::ss, ::ss]
+                res[k] = errors(got, g[k][:, v0:v1])[1]
+        if world > 2:
+            # the wider checks of the many-rank runs: this rank's token layers against its slice of the fixture (the rows of
+            # the five special tokens prove which camera / register slot every view received) and what the static-bound
+            # attention handed to its online-max pass on this rank
+            for li in (4, 11, 17, 23):
+                res[f"tokens_{li}"] = errors(cap["tokens"][li][:, :, ::ts, ::cs], g[f"tokens_{li}"][:, v0:v1])[1]
+            res["tokens_23_special"] = errors(cap["tokens"][23][:, :, :5], g["tokens_23_special"][:, v0:v1])[1]
+            assert slot0_calls and all(c == (rank == 0) for c in slot0_calls), (rank, slot0_calls)
+            for k, v in pred.items():
+                if torch.is_tensor(v):
+                    assert torch.isfinite(v).all(), k
+            res["_static"] = model.aggregator.static_softmax_stats()
         if track:                              # every rank tracks over ALL views
             res["track"] = errors(pred["track"], g["coord_preds"][-1])[1]
             res["vis"] = errors(pred["vis"], g["vis"])[1] / 5       # gated at 5e-3 like the unsharded run
@@ -99,6 +123,33 @@ def test_two_rank_sharded_forward_matches_reference(case, kv_groups, graphs, ove
     for rank, res in ret.items():
         for k, l2 in res.items():
             assert l2 < 1e-3, (rank, k, l2)   # same gate as the unsharded run (fp16 operands)
+
+
+@pytest.mark.parametrize("world,graphs,overlap", [(8, True, True), (8, False, False), (4, False, True), (4, True, False)])
+def test_many_rank_sharded_forward_at_518(world, graphs, overlap):
+    """BASELINE.json configs[3]'s machinery with more than two ranks, end to end against the reference: 8 views @ 518^2
+    (fixture full_s8_518_stress, produced by the reference modules at this size) over 8 ranks x 1 view and 4 ranks x 2 views,
+    all on cuda:0 over gloo.  Every rank runs the product's sharded forward -- own-key launch, ONE segment-mode launch over the
+    7 (3) foreign key segments under each segment's own gathered key bound, combine kernel with per-rank shifts, camera-token
+    gather over all ranks -- in the overlapped and the gather-first form, eagerly and as hipGraph segments.  Gates: the
+    unsharded ones (1e-3 l2) on every rank's slice of depth / depth_conf / world_points / world_points_conf, on pose_enc (all
+    views on every rank), on the four token layers and on the special-token rows; rank 0 alone may use slot 0 of the
+    camera / register tokens (asserted inside the worker at the call site)."""
+    from conftest import report
+
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), "full_s8_518_stress", 1, graphs, overlap, ret), nprocs=world, join=True)
+    assert set(ret.keys()) == set(range(world))
+    rep = {}
+    for rank in range(world):
+        res = dict(ret[rank])
+        st = res.pop("_static")
+        rep[f"rank{rank}"] = dict(l2=res, flagged_tiles=dict(frame=st["frame"]["flagged_tiles"], glob=st["global"]["flagged_tiles"]),
+                                  global_blocks_online_only=st["global"]["skipped_static"])
+        for k, l2 in res.items():
+            assert l2 < 1e-3, (rank, k, l2)
+    report(f"shard/world{world}/full_s8_518_stress/{'overlap' if overlap else 'gather_first'}_{'graphs' if graphs else 'eager'}", rep)
 
 
 @pytest.mark.parametrize("kv_groups,graphs,overlap", [(1, False, False), (1, False, True), (1, True, True), (4, False, False)])
