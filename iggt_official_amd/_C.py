@@ -282,22 +282,33 @@ def static_attn_est_ws_bytes(B, H, Nq, Nk):
     return int(load().iggt_flash_attn_static_est_ws_bytes(B, H, Nq, Nk))
 
 
-EST_HI_CAP = 1024   # csrc/attention_common.h
+EST_HI_CAP, EST_KS2, EST_BIAS = 1024, 16, 1048576.0   # csrc/attention_common.h
 
 
-def static_attn_est_views(est_ws, B, H, Nq):
-    """Typed views into an est_ws buffer (csrc/attention_common.h est_view; reports, tests and probes): rowshift fp32 [BH, Nq],
-    rowlist int32 [BH, Nq], rowcount int32 [BH], hicount int32 [BH], hilist int32 [BH, EST_HI_CAP], rowflag uint8 [BH, NqP]."""
+def static_attn_est_views(est_ws, B, H, Nq, Nk=None):
+    """Typed views into an est_ws buffer (csrc/attention_common.h est_view_at; reports, tests and probes): rowshift fp32
+    [BH, Nq] (stored + EST_BIAS), rowlist int32 [BH, Nq], rowcount / hicount int32 [BH], hilist int32 [BH, EST_HI_CAP],
+    rowflag uint8 [BH, NqP]."""
+    Nk = Nq if Nk is None else Nk
     BH, NqP = B * H, (Nq + 15) // 16 * 16
-    o1 = BH * Nq * 4
-    o2 = o1 + BH * Nq * 4
-    o3 = o2 + BH * 4
-    o4 = o3 + BH * 4
-    o5 = (o4 + BH * EST_HI_CAP * 4 + 15) // 16 * 16
-    return dict(rowshift=est_ws[:o1].view(torch.float32).view(BH, Nq), rowlist=est_ws[o1:o2].view(torch.int32).view(BH, Nq),
-                rowcount=est_ws[o2:o3].view(torch.int32), hicount=est_ws[o3:o4].view(torch.int32),
-                hilist=est_ws[o4:o4 + BH * EST_HI_CAP * 4].view(torch.int32).view(BH, EST_HI_CAP),
-                rowflag=est_ws[o5:o5 + BH * NqP].view(BH, NqP))
+    NqL = ((Nq + 7) // 8 + 127) // 128 * 128
+    nWG = (Nk + 31) // 32
+    off = [0]
+
+    def take(nbytes):
+        a = off[0]
+        off[0] += nbytes
+        return est_ws[a:a + nbytes]
+
+    v = dict(rowshift=take(BH * Nq * 4).view(torch.float32).view(BH, Nq), rowlist=take(BH * Nq * 4).view(torch.int32).view(BH, Nq),
+             rowcount=take(BH * 4).view(torch.int32), hicount=take(BH * 4).view(torch.int32), dense=take(BH * 4).view(torch.int32),
+             hilist=take(BH * EST_HI_CAP * 4).view(torch.int32).view(BH, EST_HI_CAP))
+    take(BH * nWG * 4), take(BH * nWG * 16), take(EST_KS2 * BH * NqL * 4), take(EST_KS2 * BH * NqL * 4)
+    off[0] = (off[0] + 15) // 16 * 16
+    take(EST_KS2 * BH * NqL * 128)
+    v["rowflag"] = take(BH * NqP).view(BH, NqP)
+    v["NqL"] = NqL
+    return v
 
 
 def static_attn_ws_bytes(B, H, Nq, Nk):

@@ -16,6 +16,7 @@
 // attention_v3.hip, whose header carries the CDNA4 mapping and the measured ladder.  The round-1 baseline kernels
 // ("v1" register-staged and the 8-wave ping-pong variant) are kept un-built under probes/legacy/.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "attention_common.h"
 #include "../../include/iggt_hip.h"
@@ -197,20 +198,39 @@ static int flash_attn_static_h16(int fmt, const void* q, const void* k, const vo
     p.qkmax = qkmax; p.flags = flags; p.guard = guard; p.guard_prev = guard_prev;
     p.static_min_l = fmt == FMT_F16 ? STATIC_MIN_L_PER_KEY_F16 * (float)Nk : STATIC_MIN_L_BF16;
     const bool est = est_ws != nullptr;
+    // IGGT_EST_DEBUG (developer bit mask, bisecting): 1 no memset of the dense marks, 2 no key scan, 4 no pre-pass, 8 no
+    // estimated-shift instantiation, 16 no row list (the online-max pass then sees no workspace), 32 no second chance
+    static int dbg = -1;
+    if (dbg < 0) {
+        const char* e = getenv("IGGT_EST_DEBUG");
+        dbg = e ? atoi(e) : 0;
+    }
     if (est) {   // row-granular hand-over + (adaptive, or est_mode = 1 without a guard) the estimated shift
-        if (est_ws_len < est_ws_size(B, H, Nq) || ((uintptr_t)est_ws % 16)) return -8;
+        if (est_ws_len < est_ws_size(B, H, Nq, Nk) || ((uintptr_t)est_ws % 16)) return -8;
         p.est_ws = (unsigned char*)est_ws;
         p.est_force = est_mode ? 1 : 0;
-        const int r = iggt_launch_attn_est_prepass(p, key_period, key_nspecial, fmt, (hipStream_t)stream);
+        const int r = iggt_launch_attn_est_prepass(p, key_period, key_nspecial, fmt, dbg, (hipStream_t)stream);
         if (r) return r;
         IGGT_CHECK_LAUNCH();
     }
-    iggt_launch_flash_attn_v3(p, rows, code / 1000 - 4, fmt, true, (hipStream_t)stream);
+    if (dbg & 8) {
+        AttnParams q2 = p;
+        q2.est_ws = nullptr;
+        iggt_launch_flash_attn_v3(q2, rows, code / 1000 - 4, fmt, true, (hipStream_t)stream);
+    } else {
+        iggt_launch_flash_attn_v3(p, rows, code / 1000 - 4, fmt, true, (hipStream_t)stream);
+    }
     IGGT_CHECK_LAUNCH();
-    if (est) {
+    if (est && !(dbg & 16)) {
         iggt_launch_attn_rowlist(p, (hipStream_t)stream);
         IGGT_CHECK_LAUNCH();
+        if (!(dbg & 32)) {
+            const int r = iggt_launch_attn_second_chance(p, fmt, (hipStream_t)stream);
+            if (r) return r;
+            IGGT_CHECK_LAUNCH();
+        }
     }
+    if (dbg & 16) p.est_ws = nullptr;
     p.qkmax = nullptr;   // gated dynamic pass: q already carries scale * log2 e
     iggt_launch_flash_attn_v3(p, rows, code / 1000 - 4, fmt, false, (hipStream_t)stream);
     IGGT_CHECK_LAUNCH();
@@ -321,8 +341,7 @@ extern "C" int iggt_flash_attn_static_ksplit(int B, int H, int Nq, int Nk) {
 
 /* bytes of the estimated-shift / row-granular workspace of iggt_flash_attn_static_* for this shape */
 extern "C" long iggt_flash_attn_static_est_ws_bytes(int B, int H, int Nq, int Nk) {
-    (void)Nk;
-    return est_ws_size(B, H, Nq);
+    return est_ws_size(B, H, Nq, Nk);
 }
 
 /* bytes of partial workspace iggt_flash_attn_static_* needs to be allowed to split the keys of this shape (0: never splits) */

@@ -46,51 +46,72 @@ struct AttnParams {
     int* guard;
     const int* guard_prev;
     int guard_retry;
-    // Round 4 -- estimated-shift static softmax + row-granular redo (attention_est.hip; one-pass launches only).
-    //   rowshift [B*H][Nq] fp32: per query row min(Cauchy-Schwarz bound, sampled row maximum + est_slack), written by the
-    //     pre-pass (attn_rowshift_kernel) over a key sample = special tokens + strided keys + keys of outlying norm;
-    //   rowflag  [B*H][NqP] bytes: 1 = the static kernel does not vouch for this row (row sum below the acceptance threshold,
-    //     or a non-finite accumulator: an fp16 numerator overflowed because the row's true maximum lies more than the
-    //     headroom above the sampled one);
-    //   rowlist  [B*H][Nq] int32 / rowcount [B*H]: the flagged rows of each (batch, head) in ascending order
-    //     (attn_rowlist_kernel) -- the online-max pass recomputes exactly those rows, 128 * QB per workgroup.
-    // The six arrays live in ONE caller-owned buffer (est_ws; the kernels derive the sub-arrays from B, H, Nq -- est_view below:
-    // six more pointers in the argument block cost the static kernel 4 scalar registers it does not have, and the spill that
-    // followed put a 16-byte reload into its tile loop).  nullptr: round-3 behaviour (norm bound, whole tiles flagged).
+    // Round 4 -- estimated-shift static softmax with a row-granular hand-over (attention_est.hip; one-pass launches only).
+    // est_ws: ONE caller-owned scratch buffer; the kernels derive its sub-arrays from B, H, Nq, Nk (est_view below -- more
+    // pointers in this argument block cost the static kernel scalar registers it does not have: the spill that followed put
+    // a 16-byte reload into its tile loop).  nullptr: round-3 behaviour (norm bound, whole 256-row tiles flagged).
     unsigned char* est_ws;
     int est_force;    // guard == nullptr: 1 = estimated shift, 0 = norm bound
+    // second-chance / list-mode launches of the static kernel (attention_est.hip): rows come from rowlist, shifts from the
+    // exact row maxima, partial results go to list-position slots
+    int list_mode;
 };
-constexpr int EST_HI_CAP = 1024;   // keys of outlying norm kept per (batch, head); more than that is not an outlier set
-// layout of est_ws: rowshift fp32 [BH][Nq] | rowlist int32 [BH][Nq] | rowcount int32 [BH] | hicount int32 [BH] |
-//                   hilist int32 [BH][EST_HI_CAP] | (16-byte aligned) rowflag bytes [BH][NqP],  NqP = Nq rounded up to 16
+constexpr int EST_HI_CAP = 1024;     // keys of outlying norm kept per (batch, head); more than that is not an outlier set
+constexpr int EST_KS2 = 16;          // key ranges of the second-chance pass
+constexpr float EST_BIAS = 1048576.f;   // rowshift is stored + 2^20 (resolution 1/8 bit): positive floats order like their bits
+// Layout of est_ws (BH = B * H; nWG = ceil(Nk / 32) key-scan workgroups; NqL = second-chance row capacity per (batch, head)
+// = Nq / 8 rounded up to 128; NqP = Nq rounded up to 16):
+//   rowshift f32 [BH][Nq]   shift of every query row (+ EST_BIAS), written by the pre-pass
+//   rowlist  i32 [BH][Nq]   ascending list of the rows the static kernel did not vouch for; rowcount i32 [BH]
+//   hicount  i32 [BH], hilist i32 [BH][EST_HI_CAP]   keys of outlying norm (hicount > EST_HI_CAP: not an outlier set, ignored)
+//   dense    i32 [BH]       set by a key-scan workgroup that saw > 4 such keys among its 32 rows
+//   wgcnt    i32 [BH][nWG], wglist i32 [BH][nWG][4]    per-workgroup finds of the key scan (no atomics), compacted into hilist
+//   pmax     f32 [EST_KS2][BH][NqL]                    second chance: exact row maxima per key range
+//   l2       f32 [EST_KS2][BH][NqL], o2 16-bit [EST_KS2][BH][NqL][64]   second chance: partial row sums / outputs
+//   rowflag  u8  [BH][NqP]  (16-byte aligned) 1 = row handed over
 struct EstView {
     float* rowshift;
     int* rowlist;
     int* rowcount;
     int* hicount;
+    int* dense;
     int* hilist;
+    int* wgcnt;
+    int* wglist;
+    float* pmax;
+    float* l2;
+    bf16_t* o2;
     unsigned char* rowflag;
-    int NqP;
+    int NqP, NqL, nWG;
 };
-__host__ __device__ inline long est_off_rowflag(long BH, long Nq) {
-    return (BH * Nq * 8 + BH * 8 + BH * EST_HI_CAP * 4 + 15) / 16 * 16;
-}
-__host__ __device__ inline long est_ws_size(int B, int H, int Nq) {
-    const long BH = (long)B * H;
-    return est_off_rowflag(BH, Nq) + BH * ((Nq + 15) / 16 * 16);
-}
-__host__ __device__ inline EstView est_view(const AttnParams& p) {
-    const long BH = (long)p.B * p.H, Nq = p.Nq;
+__host__ __device__ inline long est_nql(long Nq) { return ((Nq + 7) / 8 + 127) / 128 * 128; }
+__host__ __device__ inline EstView est_view_at(unsigned char* base, int B, int H, int Nq, int Nk) {
+    const long BH = (long)B * H, nq = Nq;
     EstView v;
-    v.rowshift = reinterpret_cast<float*>(p.est_ws);
-    v.rowlist = reinterpret_cast<int*>(p.est_ws + BH * Nq * 4);
-    v.rowcount = reinterpret_cast<int*>(p.est_ws + BH * Nq * 8);
-    v.hicount = v.rowcount + BH;
-    v.hilist = v.hicount + BH;
-    v.rowflag = p.est_ws + est_off_rowflag(BH, Nq);
-    v.NqP = (int)((Nq + 15) / 16 * 16);
+    v.NqP = (int)((nq + 15) / 16 * 16);
+    v.NqL = (int)est_nql(nq);
+    v.nWG = (Nk + 31) / 32;
+    unsigned char* w = base;
+    v.rowshift = reinterpret_cast<float*>(w);  w += BH * nq * 4;
+    v.rowlist = reinterpret_cast<int*>(w);     w += BH * nq * 4;
+    v.rowcount = reinterpret_cast<int*>(w);    w += BH * 4;
+    v.hicount = reinterpret_cast<int*>(w);     w += BH * 4;
+    v.dense = reinterpret_cast<int*>(w);       w += BH * 4;
+    v.hilist = reinterpret_cast<int*>(w);      w += BH * EST_HI_CAP * 4;
+    v.wgcnt = reinterpret_cast<int*>(w);       w += BH * (long)v.nWG * 4;
+    v.wglist = reinterpret_cast<int*>(w);      w += BH * (long)v.nWG * 16;
+    v.pmax = reinterpret_cast<float*>(w);      w += (long)EST_KS2 * BH * v.NqL * 4;
+    v.l2 = reinterpret_cast<float*>(w);        w += (long)EST_KS2 * BH * v.NqL * 4;
+    w = base + ((w - base) + 15) / 16 * 16;
+    v.o2 = reinterpret_cast<bf16_t*>(w);       w += (long)EST_KS2 * BH * v.NqL * 128;
+    v.rowflag = w;
     return v;
 }
+__host__ __device__ inline long est_ws_size(int B, int H, int Nq, int Nk) {
+    const EstView v = est_view_at(nullptr, B, H, Nq, Nk);
+    return (long)(v.rowflag - (unsigned char*)nullptr) + (long)B * H * v.NqP;
+}
+__host__ __device__ inline EstView est_view(const AttnParams& p) { return est_view_at(p.est_ws, p.B, p.H, p.Nq, p.Nk); }
 constexpr int GUARD_RETRY_DEFAULT = 16;
 constexpr int GUARD_WORDS = 8;
 // resolve the guard word(s) to "skip the static-bound kernel in this call"
@@ -160,5 +181,10 @@ int iggt_launch_flash_attn_v3(const iggt_attn::AttnParams& p, int q_rows, int kv
                               hipStream_t stream);
 int iggt_launch_attn_combine(const iggt_attn::AttnParams& p, int nslots, int q_rows, int fmt, hipStream_t stream);
 // attention_est.hip: key scan (outlying norms), row-shift pre-pass, flagged-row compaction
-int iggt_launch_attn_est_prepass(const iggt_attn::AttnParams& p, int key_period, int key_nspecial, int fmt, hipStream_t stream);
+int iggt_launch_attn_est_prepass(const iggt_attn::AttnParams& p, int key_period, int key_nspecial, int fmt, int dbg,
+                                 hipStream_t stream);
 int iggt_launch_attn_rowlist(const iggt_attn::AttnParams& p, hipStream_t stream);
+// second chance for the listed rows: exact row maxima per key range -> static kernel in list mode -> fold (attention_est.hip)
+int iggt_launch_attn_second_chance(const iggt_attn::AttnParams& p, int fmt, hipStream_t stream);
+// attention_v3.hip: the 128-row static kernel over the listed rows and one key range per workgroup
+int iggt_launch_flash_attn_v3_list(const iggt_attn::AttnParams& p, int fmt, hipStream_t stream);

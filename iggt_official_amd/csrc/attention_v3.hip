@@ -95,9 +95,15 @@ IGGT_DEVINL void guard_update(const AttnParams& p, int nwork, int rows_per_item,
         int g;
         if (skipped) {
             g = (g0 < 0 ? p.guard_retry : g0) - 1;                    // this call ran the online-max kernel only: count down
+        } else if (mode == 0 && p.est_ws != nullptr && n > 0) {
+            // the norm bound is loose here: estimate the shift from now on.  ANY flagged tile decides: under the norm bound a
+            // flagged tile is a full-length online-max workgroup, and a handful of those already cost a whole extra round
+            // (~1.5 ms at N = 43 968: bf16 "affine", 48 of 2 752 tiles flagged, 8.56 ms against 7.50 ms in estimated mode),
+            // more than the estimated-shift machinery costs when it hands nothing over (~0.5 ms)
+            mode = 1;
+            g = 0;
         } else if ((long)n * 8 > (long)nwork) {                       // > 1/8 of the work redone: static + redo loses
-            if (mode == 0 && p.est_ws != nullptr) { mode = 1; g = 0; }   // the norm bound is loose here: estimate the shift
-            else g = p.guard_retry;                                   // nothing static helps: online-max only for a while
+            g = p.guard_retry;                                        // nothing static helps: online-max only for a while
         } else {
             g = 0;
         }
@@ -123,7 +129,10 @@ IGGT_DEVINL void guard_update(const AttnParams& p, int nwork, int rows_per_item,
 // instantiation on purpose: the norm-bound kernel sits at the 256-register limit, and the same code with both paths behind a
 // run-time switch put a 16-byte spill reload into its tile loop (8-11 spilled registers instead of 2 outside the loop).  Both
 // instantiations are launched; each returns at once unless the adaptive-switch word names its mode.
-template <int QB, int KVM, int FMT, bool STATIC, bool PIN = PIN_DEFAULT, bool PART = false, bool EST = false>
+// LIST (static bound, PART, 128-row tiles only; second chance of attention_est.hip): the workgroup's rows are positions
+// [qt * 128, ...) of the (batch, head)'s list of handed-over rows, its shift the exact row maximum (+ 1) over all keys, its
+// keys range ks of EST_KS2, its results go to list-position slots.
+template <int QB, int KVM, int FMT, bool STATIC, bool PIN = PIN_DEFAULT, bool PART = false, bool EST = false, bool LIST = false>
 __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KVM * BUF_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -144,7 +153,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                 const EstView ev = est_view(p);
                 const int bh_ = work / p.qtiles;
                 nlist = ev.rowcount[bh_];
-                if ((work % p.qtiles) * (128 * QB) >= nlist) return;
+                // short lists were served by the second chance (attention_est.hip); long ones are recomputed here
+                if (nlist <= ev.NqL || (work % p.qtiles) * (128 * QB) >= nlist) return;
                 rlist = ev.rowlist + (long)bh_ * p.Nq;
             }
         }
@@ -174,6 +184,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         }
     }
     const int h = bh % p.H, b = bh / p.H;
+    if constexpr (LIST) {
+        const EstView ev = est_view(p);
+        nlist = ev.rowcount[bh];
+        if (nlist == 0 || nlist > ev.NqL || qt * (128 * QB) >= nlist) return;
+        rlist = ev.rowlist + (long)bh * p.Nq;
+    }
     const bf16_t* qb_ptr = p.q + (long)b * p.q_bs + h * 64;
     const bf16_t* kb_ptr = p.k + (long)b * p.k_bs + kseg0 * p.k_rs + h * 64;
     const bf16_t* vb_ptr = p.v + (long)b * p.v_bs + kseg0 * p.v_rs + h * 64;
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     for (int qb = 0; qb < QB; ++qb) {
         int qr = q_base + qb * 32 + frow;
         qr = qr < p.Nq ? qr : p.Nq - 1;
-        if constexpr (!STATIC) {
+        if constexpr (!STATIC || LIST) {
             if (rlist != nullptr) qr = rlist[q_base + qb * 32 + frow < nlist ? q_base + qb * 32 + frow : nlist - 1];
         }
         const bf16_t* src = qb_ptr + (long)qr * p.q_rs + 8 * fhalf;
@@ -252,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     const float c = p.scale_log2;
     // static bound: the (negated) shift enters through the accumulator input of the first QK^T MFMA of a score block
     f32x16 cinit;
+    float est_delta = 0.f;   // EST, QB = 2: shift of the lane's second row minus that of its first
     if constexpr (STATIC) {
         // PER-ROW bound: a lane owns one query column of the swapped score block, so the shift may depend on the lane's
         // query: s_ij <= |q^_i| max_j |k^_j|.  The norm is taken from the very fragments the MFMAs consume (this lane holds
@@ -260,13 +277,23 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         // SIMD -- so the lane uses the larger of its two norms.  Rows with a small |q^| (most rows, when a few outlier tokens
         // dominate max_i |q^_i|) no longer inherit the outliers' shift.
         float shift;
-        if constexpr (EST) {   // min(norm bound, sampled row maximum + headroom) per row, from the pre-pass
-            const float* rs = reinterpret_cast<const float*>(p.est_ws) + (long)bh * p.Nq;
+        if constexpr (LIST) {   // exact row maximum over all keys (the largest of the key ranges' maxima), + 1: numerators <= 2^14
+            const EstView ev = est_view(p);
+            const int lp = q_base + frow < nlist ? q_base + frow : nlist - 1;
             shift = -INFINITY;
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                const int qr = q_base + qb * 32 + frow;
-                shift = fmaxf(shift, rs[qr < p.Nq ? qr : p.Nq - 1]);
+            for (int s2 = 0; s2 < EST_KS2; ++s2) shift = fmaxf(shift, ev.pmax[((long)s2 * p.B * p.H + bh) * ev.NqL + lp]);
+            shift += 1.0f - (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
+        } else if constexpr (EST) {   // min(norm bound, sampled row maximum + headroom) per row, from the pre-pass
+            const float* rs = reinterpret_cast<const float*>(p.est_ws) + (long)bh * p.Nq;
+            const int r0 = q_base + frow;
+            shift = rs[r0 < p.Nq ? r0 : p.Nq - 1] - EST_BIAS;
+            if constexpr (QB == 2) {
+                // the lane's second row keeps ITS shift: the accumulator-input vector carries the first row's, the difference
+                // is subtracted from the second block's scores before the exponential (16 packed adds per 64-key tile).  A
+                // shared shift -- the larger of the two, as under the norm bound -- flushes the other row's numerators whenever
+                // the two differ by more than a few bits: 38 % of the rows of the "sinks" regime were handed over for that
+                const int r1 = r0 + 32;
+                est_delta = rs[r1 < p.Nq ? r1 : p.Nq - 1] - EST_BIAS - shift;
             }
             shift -= (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
         } else {
@@ -357,10 +384,23 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         float ls0 = 0.f, ls1 = 0.f, ls2 = 0.f, ls3 = 0.f;
 #pragma unroll
         for (int kvh = 0; kvh < 2; ++kvh) {
+            if (EST && QB == 2 && qb == 1) {
+                // the accumulator holds s - c + SHIFT with c of the FIRST block's row: move to this row's shift, two scores per
+                // v_pk_add_f32 (written as scalar subtractions the compiler emitted 32 v_sub_f32 per tile)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 d2 = {est_delta, est_delta};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 t = {s[kvh][r], s[kvh][r + 1]};
+                    t = t - d2;
+                    s[kvh][r] = t[0];
+                    s[kvh][r + 1] = t[1];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if constexpr (STATIC) {
-                    s[kvh][r] = __builtin_amdgcn_exp2f(s[kvh][r]);   // the accumulator already holds s - c_h + SHIFT
+                    s[kvh][r] = __builtin_amdgcn_exp2f(s[kvh][r]);   // the accumulator already holds s - c + SHIFT
                 } else {
                     const float a = __builtin_fmaf(s[kvh][r], c, -m);
                     s[kvh][r] = __builtin_amdgcn_exp2f(a);
@@ -469,9 +509,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                 bad = bad || !(chk == 0.f);
             }
             if constexpr (EST) {   // row-granular hand-over
-                const long npad = (p.Nq + 15) / 16 * 16;
-                if (fhalf == 0 && qr < p.Nq)
-                    (p.est_ws + est_off_rowflag((long)p.B * p.H, p.Nq))[(long)bh * npad + qr] = bad ? 1 : 0;
+                const EstView ev = est_view(p);
+                if (fhalf == 0 && qr < p.Nq) ev.rowflag[(long)bh * ev.NqP + qr] = bad ? 1 : 0;
             } else {
                 weak = weak || (qr < p.Nq && bad);
             }
@@ -483,9 +522,15 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                 qr = rlist[live ? qr : nlist - 1];
             }
         }
+        if constexpr (LIST) live = qr < nlist;
         if (live) {
             bf16_t* dst = ob_ptr + (long)qr * p.o_rs + 4 * fhalf;
-            if constexpr (PART) {   // partial slot (slot0 + ks): dense [slot][B][Nq][H * 64] rows, l as [slot][B][H][Nq]
+            if constexpr (LIST) {   // list-position slot of key range ks: [ks][bh][position][64], row sum beside it
+                const EstView ev = est_view(p);
+                const long li = ((long)ks * p.B * p.H + bh) * ev.NqL + qr;
+                dst = ev.o2 + li * 64 + 4 * fhalf;
+                if (fhalf == 0) ev.l2[li] = l;
+            } else if constexpr (PART) {   // partial slot (slot0 + ks): dense [slot][B][Nq][H * 64] rows, l as [slot][B][H][Nq]
                 const long slot = p.slot0 + ks - ((p.seg_len > 0 && p.skip_seg >= 0 && ks > p.skip_seg) ? 1 : 0);
                 dst = p.o_part + ((slot * p.B + b) * p.Nq + qr) * (long)(p.H * 64) + h * 64 + 4 * fhalf;
                 if (fhalf == 0) {
@@ -570,6 +615,30 @@ static void launch_v3(const AttnParams& p_in, int q_rows, int kvm, hipStream_t s
     }
 }
 
+#ifdef IGGT_ATTN_EST_TU
+// attention_v3_est.hip: the estimated-shift instantiations only, in their own translation unit so that they can be built
+// with -mllvm -amdgpu-sched-strategy=max-ilp (iggt_official_amd/build_ext.py): under the default strategy the f16 256-row
+// instantiation allocates 255 VGPRs + 7 spilled with a 16-byte reload inside the tile loop, under max-ilp 251 and none; the
+// norm-bound and online-max kernels keep the flags their measurements were taken with.
+int iggt_launch_flash_attn_v3_est(const AttnParams& p, int q_rows, int kvm, int fmt, hipStream_t stream) {
+    if (fmt == FMT_F16) launch_v3<FMT_F16, true, false, true>(p, q_rows, kvm, stream);
+    else launch_v3<FMT_BF16, true, false, true>(p, q_rows, kvm, stream);
+    return 0;
+}
+#else
+int iggt_launch_flash_attn_v3_est(const AttnParams& p, int q_rows, int kvm, int fmt, hipStream_t stream);
+
+int iggt_launch_flash_attn_v3_list(const AttnParams& p_in, int fmt, hipStream_t stream) {
+    AttnParams p = p_in;
+    const EstView ev = est_view(p);
+    p.ksplit = EST_KS2; p.slot0 = 0; p.seg_len = 0; p.skip_seg = -1; p.seg_kmax = nullptr;
+    p.qtiles = ev.NqL / 128;
+    const dim3 grid((unsigned)((long)p.B * p.H * p.qtiles * EST_KS2)), block(256);
+    if (fmt == FMT_F16) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 2, FMT_F16, true, PIN_DEFAULT, true, false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<1, 2, FMT_BF16, true, PIN_DEFAULT, true, false, true>), grid, block, 0, stream, p);
+    return 0;
+}
+
 int iggt_launch_flash_attn_v3(const AttnParams& p, int q_rows, int kvm, int fmt, bool static_bound, hipStream_t stream) {
     if (static_bound && p.ksplit > 0) {
         if (fmt == FMT_F16) launch_v3<FMT_F16, true, true>(p, q_rows, kvm, stream);
@@ -577,10 +646,8 @@ int iggt_launch_flash_attn_v3(const AttnParams& p, int q_rows, int kvm, int fmt,
     } else if (static_bound) {
         if (fmt == FMT_F16) launch_v3<FMT_F16, true, false>(p, q_rows, kvm, stream);
         else launch_v3<FMT_BF16, true, false>(p, q_rows, kvm, stream);
-        if (p.est_ws != nullptr) {   // the estimated-shift instantiation: runs when the adaptive switch names mode 1
-            if (fmt == FMT_F16) launch_v3<FMT_F16, true, false, true>(p, q_rows, kvm, stream);
-            else launch_v3<FMT_BF16, true, false, true>(p, q_rows, kvm, stream);
-        }
+        // the estimated-shift instantiation: runs when the adaptive switch names mode 1
+        if (p.est_ws != nullptr) iggt_launch_flash_attn_v3_est(p, q_rows, kvm, fmt, stream);
     } else {
         if (fmt == FMT_F16) launch_v3<FMT_F16, false, false>(p, q_rows, kvm, stream);
         else launch_v3<FMT_BF16, false, false>(p, q_rows, kvm, stream);
@@ -596,3 +663,4 @@ int iggt_launch_attn_combine(const AttnParams& p_in, int nslots, int q_rows, int
     else hipLaunchKernelGGL(attn_combine_kernel<FMT_BF16>, grid, block, 0, stream, p, nslots, q_rows);
     return 0;
 }
+#endif  // IGGT_ATTN_EST_TU

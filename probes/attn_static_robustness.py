@@ -7,10 +7,13 @@ time of the global attention at the bench shape (N = 43 968, 16 heads, fp16 and 
   sinks      affine + 8 "attention sink" keys with 10x the norm of the rest (they set max|k|, the bound of every row)
   registers  affine + the 5 special-token rows of every view with 30x the query norm of the patch rows
 
-in four launch modes: online-max kernel alone (the fallback everything is measured against); static bound without the adaptive
-switch (static pass, then every flagged tile again); static bound with the switch, FIRST call of a cold call site; and its
-steady state (mean over 34 calls = two retry periods: 16 calls online-max only, 1 call static + redo, ...).
-Usage: python probes/attn_static_robustness.py > profiles/r03_attn_static_robustness.txt   (on the GPU box)"""
+in these launch modes: online-max kernel alone (the fallback everything is measured against); static norm bound without the
+adaptive switch (static pass, then every flagged tile again); round 3's adaptive launch (norm bound or online-max only: no
+workspace), steady state = mean over 34 calls (two retry periods); round 4: the ESTIMATED shift forced (pre-pass + static
+kernel + row-granular redo, csrc/attention_est.hip) and the round-4 adaptive launch (norm bound -> estimated shift -> online-max
+only) from a cold call site: first call, second call, steady state, with the mode the switch settled in and the rows / tiles
+handed to the online-max pass.
+Usage: python probes/attn_static_robustness.py > profiles/r04_attn_static_robustness.txt   (on the GPU box)"""
 import os
 import sys
 
@@ -64,8 +67,8 @@ def timed(fn, reps):
 
 def main():
     print(f"# global attention, {VIEWS} views @ 518^2: Nq = Nk = {T}, 16 heads x 64; {torch.cuda.get_device_name(0)}")
-    print(f"# {'operands':8s} {'input':10s} {'flagged tiles':>16s} {'online-max':>11s} {'static,no switch':>17s} "
-          f"{'switch: 1st call':>17s} {'switch: steady':>15s} {'steady / online':>16s}")
+    print(f"# {'operands':8s} {'input':10s} {'flagged tiles':>16s} {'online-max':>11s} {'norm bound,no sw':>17s} "
+          f"{'r3 switch steady':>17s} {'est forced':>11s} {'r4: 1st / 2nd / steady':>26s} {'steady/online':>14s}  r4 state")
     for dt, name in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
         for kind in ("noise", "affine", "sinks", "registers"):
             qkv, qkmax = make(kind, dt)
@@ -86,11 +89,30 @@ def main():
             ntiles = H * ((T + 255) // 256)
             nflag = int(flags[:ntiles].sum())
             guard = _C.new_attn_guard("cuda")
-            t_first = timed(lambda: static(guard), 1)[0]
+            timed(lambda: static(guard), 1)
             steady = timed(lambda: static(guard), 34)
-            t_steady = sum(steady) / len(steady)
-            print(f"  {name:8s} {kind:10s} {nflag:7d} / {ntiles:5d} {t_on:9.2f}ms {t_st:15.2f}ms {t_first:15.2f}ms "
-                  f"{t_steady:13.2f}ms {t_steady / t_on:15.3f}x   guard={guard.tolist()}")
+            t_r3 = sum(steady) / len(steady)
+            est_ws = torch.zeros(_C.static_attn_est_ws_bytes(1, H, T, T), dtype=torch.uint8, device="cuda")
+
+            def est(guard=None, force=1):
+                _C.flash_attn_d64_static(*args, qkmax, flags, 0, None, guard, None, est_ws=est_ws, key_period=P, key_nspecial=5,
+                                         est_mode=force)
+
+            est()
+            t_est = sorted(timed(est, 7))[3]
+            views = _C.static_attn_est_views(est_ws, 1, H, T)
+            rows_forced = int(views["rowcount"].sum())
+            hi = views["hicount"].tolist()
+            g4 = _C.new_attn_guard("cuda")
+            t1 = timed(lambda: est(g4, 0), 1)[0]
+            t2 = timed(lambda: est(g4, 0), 1)[0]
+            steady = timed(lambda: est(g4, 0), 34)
+            t_r4 = sum(steady) / len(steady)
+            st = g4.tolist()
+            mode = "online-max only" if st[0] > 0 or st[1] < 0 else ("estimated shift" if st[4] == 1 else "norm bound")
+            print(f"  {name:8s} {kind:10s} {nflag:7d} / {ntiles:5d} {t_on:9.2f}ms {t_st:15.2f}ms {t_r3:15.2f}ms {t_est:9.2f}ms "
+                  f"{t1:8.2f} /{t2:6.2f} /{t_r4:6.2f}ms {t_r4 / t_on:12.3f}x  {mode}; work items redone {st[1]} of {st[2]}, rows "
+                  f"{st[5]}; est forced: rows redone {rows_forced} of {H * T}, outlying-norm keys per head {min(hi)}..{max(hi)}")
 
 
 if __name__ == "__main__":

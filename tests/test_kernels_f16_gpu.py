@@ -41,9 +41,12 @@ def test_gemm_f16_mixed_operands_rejected(C):
 
 
 @pytest.mark.parametrize("M,N,K,mode", [(5000, 4096, 1024, "gelu"), (4122, 1024, 4096, "acc"), (2738, 1024, 640, "remap"),
-                                        (43968, 3072, 1024, "plain"), (300, 256, 128, "gelu")])
+                                        (43968, 3072, 1024, "plain"), (300, 256, 128, "gelu"),
+                                        (9000, 4096, 1024, "gelu"), (8448, 1024, 4096, "acc")])
 def test_gemm_f16_epilogues(C, M, N, K, mode):
-    """Both GEMM kernels (256x256 LDS-DMA ping-pong for the large shapes, 128x128 for the small one)."""
+    """All three GEMM kernels: 1 024 <= M < 8 192 is the 256 x 128 two-workgroups-per-CU kernel (gemm_bf16_duo.hip: the
+    per-rank shapes of a sharded run), M >= 8 192 the 256 x 256 LDS-DMA ping-pong kernel (gemm_bf16_t256.hip: ragged last
+    row tile, GELU from the LDS table / LayerScale-accumulate epilogues), the small shape the 128 x 128 kernel."""
     a = _rand((M, K), 70, dtype=F16)
     w = _rand((N, K), 71, K ** -0.5, dtype=F16)
     bias, gamma = _rand((N,), 72, 0.1), _rand((N,), 73)
@@ -53,7 +56,7 @@ def test_gemm_f16_epilogues(C, M, N, K, mode):
         C.gemm_h16(a, w, out, bias=bias, act=1)
         mx, l2 = _relerr(out, torch.nn.functional.gelu(base))
         report(f"gemm_f16_gelu_{M}", dict(max=mx, l2=l2))
-        assert mx < 8e-4 and l2 < 4e-4  # one fp16 rounding of the output (2^-11 relative) + A&S erfc (1.5e-7)
+        assert mx < 8e-4 and l2 < 4e-4  # one fp16 rounding of the output (2^-11 relative) + A&S erfc (1.5e-7) / table (2.5e-6)
     elif mode == "acc":
         x = _rand((M, N), 74)
         ref = x.double() + gamma.double() * base
@@ -74,6 +77,31 @@ def test_gemm_f16_epilogues(C, M, N, K, mode):
         rows = torch.arange(0, M, 97, device="cuda")
         base_s = a[rows].double() @ w.double().t() + bias.double()
         assert not torch.isnan(out).any() and _relerr(out[rows], base_s)[0] < 2e-5
+
+
+def test_gemm_gelu_table_against_erf(C):
+    """The fc1 epilogue of the 256 x 256 kernel evaluates GELU from an LDS table of Phi (gemm_bf16_t256.hip, round 4).  A GEMM
+    whose result IS a chosen pre-activation (one non-zero operand column, unit weights) sweeps x over [-10, 10] and beyond
+    the table; against torch's erf GELU (reference iggt/layers/mlp.py:34, nn.GELU()) in fp64 the error must stay within one
+    fp16 rounding of the result plus the table's 2.5e-6."""
+    M, N, K = 9216, 1024, 128
+    xs = torch.cat([torch.linspace(-10, 10, M - 16, device="cuda"),
+                    torch.tensor([-65000., -100., -8.0, -7.99, -1e-4, 0., 1e-4, 7.99, 8.0, 8.01, 100., 3000., 65000., 0.5, -0.5, 1.0],
+                                 device="cuda")])
+    a = torch.zeros(M, K, dtype=F16, device="cuda")
+    a[:, 0] = xs.to(F16)
+    w = torch.zeros(N, K, dtype=F16, device="cuda")
+    w[:, 0] = 1.0
+    out = torch.empty(M, N, dtype=F16, device="cuda")
+    C.gemm_h16(a, w, out, act=1)
+    x = a[:, 0].double()
+    ref = torch.nn.functional.gelu(x).clamp(-65504, 65504)
+    got = out.double()
+    assert torch.equal(out[:, :1].expand(-1, N), out)                 # every column is the same function of x
+    err = (got[:, 0] - ref).abs()
+    tol = ref.abs() * 2.0 ** -11 + 3e-6
+    assert bool((err <= tol).all()), (float((err - tol).max()), float(x[(err - tol).argmax()]))
+    report("gemm_f16_gelu_table", dict(max_abs=float(err.max()), max_abs_at=float(x[err.argmax()])))
 
 
 def test_gemm_f16_store_saturates(C):
