@@ -93,8 +93,8 @@ class Workspace:
         return self.get(name, (rows, cols + pad), dtype, device)[:, :cols]
 
 
-def _h16_weight(lin: nn.Linear, dt: torch.dtype, pad: int = 0):
-    w = lin.weight.detach().to(dt)
+def _h16_weight(w: torch.Tensor, dt: torch.dtype, pad: int = 0):
+    w = w.detach().to(dt)
     if pad == 0:
         return w.contiguous()
     buf = torch.zeros(w.shape[0], w.shape[1] + pad, dtype=dt, device=w.device)
@@ -102,10 +102,73 @@ def _h16_weight(lin: nn.Linear, dt: torch.dtype, pad: int = 0):
     return buf[:, :w.shape[1]]
 
 
-def _h16_residual(lin: nn.Linear, dt: torch.dtype):
+def _h16_residual(w: torch.Tensor, dt: torch.dtype):
     """dW = W - round16(W), itself stored in 16 bits (mean-input compensation, csrc/elementwise.hip)."""
-    w = lin.weight.detach().float()
+    w = w.detach().float()
     return (w - w.to(dt).float()).to(dt).contiguous()
+
+
+# Range folding (round 4).  fp16 operands hold |w| <= 65504; a checkpoint whose weights exceed that used to be sent to bf16
+# operands as a whole -- the mode that sits 6e-3 from the fp32 reference.  A block's four GEMMs sit between per-channel affines
+# that commute with a power-of-two rescaling EXACTLY (no rounding: only exponents change):
+#   qkv / fc1 input column c   <->  norm1 / norm2 weight and bias of channel c   (x_n W^T = (x_n s)(W / s)^T)
+#   proj / fc2 output row n    <->  LayerScale gamma_n and the bias b_n          (gamma (W x + b) = (gamma s)((W / s) x + b / s))
+#   proj input column n        <->  row n of the V third of qkv and its bias     (attention is linear in V)
+# so an outlying column / row is brought back to O(1) at pack time and its partner absorbs the factor.  This is the
+# re-parametrisation freedom a trained checkpoint may sit anywhere in (a LayerNorm scale of 1e-5 in front of weights of 1e5);
+# the activations between the two partners then have ordinary magnitudes as well.  Only slices whose largest entry exceeds
+# FOLD_HI are touched, so ordinary checkpoints pack bit-identically to round 3.  What cannot be folded (rows of qkv's Q / K
+# thirds and of fc1, columns of fc2: a non-linearity follows) and still exceeds the range sends THAT BLOCK to bf16 operands.
+FOLD_HI = 1024.0
+
+
+def _pow2_scale(w: torch.Tensor, dim: int):
+    """Per-slice power of two for the slices of `w` along `dim` (dim = 0: columns, 1: rows) that are outliers AS A WHOLE: the
+    decision uses the slice's MEDIAN magnitude, not its maximum -- an outlying row raises the maximum of every column it
+    crosses (and vice versa) but not their medians, and folding the wrong partner would push ordinary entries into fp16's
+    subnormal range.  A slice is rescaled when its maximum exceeds FOLD_HI and its median is > 64x the typical slice median; the
+    factor brings its median back to the typical one."""
+    a = w.abs()
+    med = a.median(dim=dim).values.clamp_min(1e-30)
+    typical = med.median().clamp_min(1e-30)
+    s = torch.exp2(torch.round(torch.log2(med / typical)))
+    hit = (a.amax(dim=dim) > FOLD_HI) & (med > 64.0 * typical)
+    return torch.where(hit, s, torch.ones_like(s))
+
+
+def fold_ranges(wq, bq, wp, bp, w1, w2, b2, n1w, n1b, n2w, n2b, g1, g2):
+    """Exact power-of-two re-parametrisation of one block (fp32 tensors in, fp32 tensors out; see FOLD_HI above).  Returns the
+    thirteen tensors in the same order plus the number of slices that were rescaled."""
+    C = wp.shape[0]
+    touched = 0
+    # qkv input columns <-> norm1
+    s = _pow2_scale(wq, 0)
+    touched += int((s != 1).sum())
+    wq, n1w, n1b = wq / s[None, :], n1w * s, n1b * s
+    # proj input columns <-> V rows of qkv
+    r = _pow2_scale(wp, 0)
+    touched += int((r != 1).sum())
+    wp = wp / r[None, :]
+    wq = torch.cat([wq[:2 * C], wq[2 * C:] * r[:, None]], 0)
+    if bq is not None:
+        bq = torch.cat([bq[:2 * C], bq[2 * C:] * r], 0)
+    # proj output rows <-> LayerScale 1
+    s = _pow2_scale(wp, 1)
+    touched += int((s != 1).sum())
+    wp, g1 = wp / s[:, None], g1 * s
+    if bp is not None:
+        bp = bp / s
+    # fc1 input columns <-> norm2
+    s = _pow2_scale(w1, 0)
+    touched += int((s != 1).sum())
+    w1, n2w, n2b = w1 / s[None, :], n2w * s, n2b * s
+    # fc2 output rows <-> LayerScale 2
+    s = _pow2_scale(w2, 1)
+    touched += int((s != 1).sum())
+    w2, g2 = w2 / s[:, None], g2 * s
+    if b2 is not None:
+        b2 = b2 / s
+    return wq, bq, wp, bp, w1, w2, b2, n1w, n1b, n2w, n2b, g1, g2, touched
 
 
 MEAN_SAMPLE_ROWS = 1024  # the column mean is taken over ~this many evenly spaced rows (sampling error sigma / 32)
@@ -150,29 +213,57 @@ class Block(nn.Module):
         params or the operand format change."""
         ps = (self.attn.qkv.weight, self.attn.proj.weight, self.mlp.fc1.weight, self.mlp.fc2.weight)
         dt = precision.operand_dtype()
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (dt, precision.mean_compensation_sites())
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (dt, precision.mean_compensation_sites(),
+                                                                              precision.range_folding())
         if self._packed_key != key:
             if self._packed is not None:
                 graphs.buffers_changed()    # the old packs are freed below; captured graphs hold their addresses
             dev = ps[0].device
-            for nm, w_ in zip(("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"), ps):
-                precision.check_operand_range(nm + ".weight", w_, dt)
             f32 = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
             ones = lambda: torch.ones(self.dim, device=dev)  # noqa: E731
+            wq, wp, w1, w2 = (f32(p) for p in ps)
+            bq, bp, b1, b2 = (f32(l.bias) for l in (self.attn.qkv, self.attn.proj, self.mlp.fc1, self.mlp.fc2))
+            g1 = f32(self.ls1.gamma) if isinstance(self.ls1, LayerScale) else ones()
+            g2 = f32(self.ls2.gamma) if isinstance(self.ls2, LayerScale) else ones()
+            n1w, n1b, n2w, n2b = f32(self.norm1.weight), f32(self.norm1.bias), f32(self.norm2.weight), f32(self.norm2.bias)
+            folded = 0
+            if dt == torch.float16 and precision.range_folding():
+                # one device-side reduction decides whether anything has to be folded at all (the common case: nothing)
+                if float(torch.stack([t.abs().amax() for t in (wq, wp, w1, w2)]).amax()) > FOLD_HI:
+                    wq, bq, wp, bp, w1, w2, b2, n1w, n1b, n2w, n2b, g1, g2, folded = fold_ranges(
+                        wq, bq, wp, bp, w1, w2, b2, n1w, n1b, n2w, n2b, g1, g2)
+            if dt == torch.float16:
+                worst = float(torch.stack([t.abs().amax() for t in (wq, wp, w1, w2)]).amax())
+                if not (worst <= 65504.0):
+                    if not precision.range_folding():
+                        precision.check_operand_range("block weight", torch.tensor(worst), dt)   # raises (round-3 behaviour)
+                    # what is left beyond the range has no exact partner to fold into: this block alone runs on bf16 operands
+                    import logging
+
+                    logging.getLogger(__name__).warning(
+                        "a transformer block keeps max |w| = %.4g after range folding: it runs on bf16 operands (the others "
+                        "stay on fp16)", worst)
+                    dt = torch.bfloat16
+                    wq, wp, w1, w2 = (f32(p) for p in ps)
+                    bq, bp, b2 = f32(self.attn.qkv.bias), f32(self.attn.proj.bias), f32(self.mlp.fc2.bias)
+                    g1 = f32(self.ls1.gamma) if isinstance(self.ls1, LayerScale) else ones()
+                    g2 = f32(self.ls2.gamma) if isinstance(self.ls2, LayerScale) else ones()
+                    n1w, n1b = f32(self.norm1.weight), f32(self.norm1.bias)
+                    n2w, n2b = f32(self.norm2.weight), f32(self.norm2.bias)
+                    folded = 0
+            cont = lambda t: None if t is None else t.contiguous()  # noqa: E731
             self._packed = dict(
-                w_qkv=_h16_weight(self.attn.qkv, dt, ROW_PAD), b_qkv=f32(self.attn.qkv.bias),
-                w_proj=_h16_weight(self.attn.proj, dt), b_proj=f32(self.attn.proj.bias),
-                w_fc1=_h16_weight(self.mlp.fc1, dt), b_fc1=f32(self.mlp.fc1.bias),
-                w_fc2=_h16_weight(self.mlp.fc2, dt), b_fc2=f32(self.mlp.fc2.bias),
-                g1=f32(self.ls1.gamma) if isinstance(self.ls1, LayerScale) else ones(),
-                g2=f32(self.ls2.gamma) if isinstance(self.ls2, LayerScale) else ones(),
-                n1w=f32(self.norm1.weight), n1b=f32(self.norm1.bias),
-                n2w=f32(self.norm2.weight), n2b=f32(self.norm2.bias),
+                w_qkv=_h16_weight(wq, dt, ROW_PAD), b_qkv=cont(bq),
+                w_proj=_h16_weight(wp, dt), b_proj=cont(bp),
+                w_fc1=_h16_weight(w1, dt), b_fc1=cont(b1),
+                w_fc2=_h16_weight(w2, dt), b_fc2=cont(b2),
+                g1=g1.contiguous(), g2=g2.contiguous(),
+                n1w=n1w.contiguous(), n1b=n1b.contiguous(), n2w=n2w.contiguous(), n2b=n2b.contiguous(),
+                folded_slices=folded,
             )
-            comp = precision.mean_compensation_sites()
-            for n, lin in (("qkv", self.attn.qkv), ("proj", self.attn.proj), ("fc1", self.mlp.fc1),
-                           ("fc2", self.mlp.fc2)):
-                self._packed["dw_" + n] = _h16_residual(lin, dt) if n in comp else None
+            comp = precision.mean_compensation_sites() if dt == torch.float16 else frozenset()
+            for n, w_ in (("qkv", wq), ("proj", wp), ("fc1", w1), ("fc2", w2)):
+                self._packed["dw_" + n] = _h16_residual(w_, dt) if n in comp else None
             if self.attn.qk_norm:
                 self._packed.update(qw=f32(self.attn.q_norm.weight), qb=f32(self.attn.q_norm.bias),
                                     kw=f32(self.attn.k_norm.weight), kb=f32(self.attn.k_norm.bias))
@@ -205,11 +296,12 @@ class Block(nn.Module):
         dev = x2d.device
         pk = self.packed()
         H = self.attn.num_heads
-        dt = pk["w_qkv"].dtype  # 16-bit operand format of this forward
-        xn = ws.get_padded("xn", T, C, dt, dev)
-        qkv = ws.get("qkv", (T, 3 * C), dt, dev)
-        ao = ws.get("ao", (T, C), dt, dev)
-        hid = ws.get("hid", (T, pk["w_fc1"].shape[0]), dt, dev)
+        dt = pk["w_qkv"].dtype  # 16-bit operand format of this block (bf16 for a block whose weights could not be folded)
+        alt = "" if dt == precision.operand_dtype() else "_alt"   # its own buffers: no reallocation when neighbours differ
+        xn = ws.get_padded("xn" + alt, T, C, dt, dev)
+        qkv = ws.get("qkv" + alt, (T, 3 * C), dt, dev)
+        ao = ws.get("ao" + alt, (T, C), dt, dev)
+        hid = ws.get("hid" + alt, (T, pk["w_fc1"].shape[0]), dt, dev)
 
         sat = precision.debug_saturation()
         _C.layernorm(x2d, pk["n1w"], pk["n1b"], xn, self.norm1.eps)
@@ -243,13 +335,13 @@ class Block(nn.Module):
                 G = kv_gather.kv_groups
                 hg = H // G
                 D = 2 * hg * 64
-                kv_local = ws.get("kv_local", (G, T, D), dt, dev)
+                kv_local = ws.get("kv_local" + alt, (G, T, D), dt, dev)
                 _C.qknorm_rope(qkv, qkv, kv_local[0], kv_local[0][:, hg * 64:], *qk_args, heads_per_group=hg,
                                k_group_stride=T * D, v_group_stride=T * D)
                 grouped = (G, hg, D, kv_gather.gather_kv_groups(kv_local))
             else:
                 gather = kv_gather.all_gather_kv if hasattr(kv_gather, "all_gather_kv") else kv_gather
-                kv_local = ws.get("kv_local", (T, 2 * C), dt, dev)
+                kv_local = ws.get("kv_local" + alt, (T, 2 * C), dt, dev)
                 _C.qknorm_rope(qkv, qkv, kv_local, kv_local[:, C:], *qk_args, **sk)
                 assert batch == 1
                 if static and q_rows_per_wg == 0 and hasattr(kv_gather, "all_gather_kv_begin") and kv_gather.active:
@@ -333,7 +425,7 @@ class Block(nn.Module):
         overlap = False (IGGT_GATHER_OVERLAP=0): the gather completes first; same kernels."""
         W, r = shard.world, shard.rank
         dt, dev = qkv.dtype, qkv.device
-        o_part = ws.get("attn_opart", (W, 1, T, C), dt, dev)
+        o_part = ws.get("attn_opart" + ("" if dt == precision.operand_dtype() else "_alt"), (W, 1, T, C), dt, dev)
         l_part = ws.get("attn_lpart", (W, 1, H, T), torch.float32, dev)
         c_part = ws.get("attn_cpart", (W, 1, H, T), torch.float32, dev)
         flags = ws.get("attn_flags", (H * ((T + 127) // 128),), torch.int32, dev)

@@ -175,6 +175,22 @@ def saturation_report() -> dict:
     return out
 
 
+# Range folding of the trunk blocks' weights at pack time (layers/blocks.py fold_ranges): exact power-of-two rescaling of
+# outlying weight columns / rows against the LayerNorm / LayerScale / V-projection partner that absorbs the factor, so that a
+# checkpoint with weights beyond +-65504 keeps fp16 operands; a block that still does not fit runs on bf16 alone.
+# IGGT_RANGE_FOLD=0: round-3 behaviour (such a checkpoint is rejected at pack time / sent to bf16 by load_checkpoint).
+_range_fold = os.environ.get("IGGT_RANGE_FOLD", "1") != "0"
+
+
+def range_folding() -> bool:
+    return _range_fold
+
+
+def set_range_folding(on: bool) -> None:
+    global _range_fold
+    _range_fold = bool(on)
+
+
 def check_operand_range(name: str, w: torch.Tensor, dt: torch.dtype) -> None:
     """Weights are converted with a plain cast (no clamp): a value beyond the fp16 range would become inf and poison every
     output.  Called once per pack (blocks.py); the comparison runs on the device, the verdict is read back once."""

@@ -107,8 +107,12 @@ def mutual_reachability_mst(x: torch.Tensor, min_samples: int, _kernels=None):
         key = torch.where(w2 == torch.repeat_interleave(wmin, counts), (lo * M + hi).double(), torch.full_like(w2, big, dtype=torch.float64))
         ekey = _segment_min(key, counts).long()                    # lo * M + hi < 2^53: exact in float64
         elo, ehi = ekey // M, ekey % M
-        ukey, first = np.unique(ekey.cpu().numpy(), return_index=True)   # two components may pick the same edge: keep it once
-        first = torch.from_numpy(first).to(dev)
+        # two components may pick the same edge: keep it once -- first occurrence per key, keys ascending (what numpy's
+        # unique(return_index=True) returned when this step still copied the keys to the host): stable device sort + run heads
+        skey, sidx = torch.sort(ekey, stable=True)
+        head = torch.ones_like(skey, dtype=torch.bool)
+        head[1:] = skey[1:] != skey[:-1]
+        first = sidx[head]
         eu.append(elo[first])
         ev.append(ehi[first])
         ew.append(torch.sqrt(wmin[first]))

@@ -4,8 +4,9 @@
 in the model with the same shape are returned; shape mismatches, model keys the checkpoint lacks and checkpoint keys the
 model lacks are reported through `logger`.  `load_checkpoint` is the whole demo.py:112-119 sequence plus what the MI355X
 operand format needs: the official weights were trained under bf16 autocast, the trunk runs on fp16 MFMA operands by
-default (iggt_official_amd/precision.py), so every GEMM weight is checked against the fp16 range (|w| <= 65504) and the
-model is switched to bf16 operands -- loudly -- if a checkpoint does not fit."""
+default (iggt_official_amd/precision.py), so every GEMM weight is checked against the fp16 range (|w| <= 65504): weights
+beyond it are range-folded exactly at pack time (layers/blocks.py fold_ranges, round 4), a block that still does not fit runs
+on bf16 operands alone, and with IGGT_RANGE_FOLD=0 the whole trunk is switched to bf16 operands -- loudly -- as in round 3."""
 import logging
 
 import torch
@@ -67,8 +68,15 @@ def load_checkpoint(model, path_or_state_dict, logger=None, map_location="cpu"):
     missing, unexpected = model.load_state_dict(aligned, strict=False)
     worst, bad = operand_range_report(aligned)
     if bad and precision.operand_dtype() == torch.float16:
-        log.warning(f"{len(bad)} trunk weight tensors exceed the fp16 range (first: {bad[0]}); switching the trunk to bf16 "
-                    "operands (precision.set_operand_dtype): outputs then follow the reference's autocast(bf16) GPU mode")
-        precision.set_operand_dtype(torch.bfloat16)
+        if precision.range_folding():
+            # round 4: exact power-of-two range folding at pack time (layers/blocks.py fold_ranges) keeps fp16 operands for
+            # weights that are beyond the range only through the checkpoint's parametrisation; a block with entries no partner
+            # can absorb runs on bf16 alone
+            log.warning(f"{len(bad)} trunk weight tensors exceed the fp16 range (first: {bad[0]}): they are range-folded at "
+                        "pack time; blocks that still do not fit run on bf16 operands individually")
+        else:
+            log.warning(f"{len(bad)} trunk weight tensors exceed the fp16 range (first: {bad[0]}); switching the trunk to "
+                        "bf16 operands (precision.set_operand_dtype): outputs then follow the reference's autocast(bf16) mode")
+            precision.set_operand_dtype(torch.bfloat16)
     return {"loaded": len(aligned), "missing": list(missing), "unexpected": list(unexpected), "max_abs_weight": worst,
             "beyond_fp16": bad}

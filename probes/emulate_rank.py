@@ -11,7 +11,7 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 SIZE = int(sys.argv[3]) if len(sys.argv) > 3 else 518
 
 
-from iggt_official_amd.dist import EmulatedShard  # noqa: E402
+from probes.emulated_shard import EmulatedShard  # noqa: E402
 
 FakeShard = lambda: EmulatedShard(N, int(os.environ["IGGT_EMU_RANK"]) if "IGGT_EMU_RANK" in os.environ else None)  # noqa: E731
 
