@@ -168,10 +168,10 @@ constexpr float STATIC_MIN_L_BF16 = 1e-30f;
 // estimated-shift mode: headroom (log2 units) between the sampled row maximum and the top of the fp16 range; the sampled
 // maximum itself lands on 2^(STATIC_SHIFT_F16 - slack), which must stay above the acceptance threshold Nk * 2^-13 (host side)
 inline float est_slack_for(int Nk) {
-    int lg = 0;
-    while ((1L << lg) < (long)Nk) ++lg;                  // ceil(log2 Nk)
-    const int s = (int)STATIC_SHIFT_F16 - (lg - 13) - 1;
-    return (float)(s > 12 ? 12 : (s < 4 ? 4 : s));
+    // largest s with 2^(15 - s) >= 1.25 * Nk * 2^-13, i.e. s <= 28 - log2(Nk) - 0.33; at most 12
+    int s = 12;
+    while (s > 4 && (float)(1L << (15 - s)) < 1.25f * (float)Nk * STATIC_MIN_L_PER_KEY_F16) --s;
+    return (float)s;
 }
 
 }  // namespace iggt_attn

@@ -55,6 +55,20 @@ namespace {
 
 constexpr float DEFER_THR = 4.0f;  // log2 units: P <= 16
 
+// A/B builds of the estimated-shift instantiation (probes/build_alt.py est_*): IGGT_EST_CZERO applies BOTH query blocks' shifts
+// by packed adds in front of the exponentials and feeds the score MFMAs a zero accumulator (no 16-register shift vector);
+// IGGT_EST_NODELTA gives a lane's two rows one shared shift (the larger), as under the norm bound.
+#ifdef IGGT_EST_CZERO
+constexpr bool EST_CZERO = true;
+#else
+constexpr bool EST_CZERO = false;
+#endif
+#ifdef IGGT_EST_NODELTA
+constexpr bool EST_NODELTA = true;
+#else
+constexpr bool EST_NODELTA = false;
+#endif
+
 #ifdef IGGT_ATTN_NO_PIN   // A/B builds only (probes/build_alt.py)
 constexpr bool PIN_DEFAULT = false;
 #else
@@ -269,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     // static bound: the (negated) shift enters through the accumulator input of the first QK^T MFMA of a score block
     f32x16 cinit;
     float est_delta = 0.f;   // EST, QB = 2: shift of the lane's second row minus that of its first
+    float est_shift0 = 0.f;  // EST_CZERO builds: the first row's shift (the accumulator input stays zero)
     if constexpr (STATIC) {
         // PER-ROW bound: a lane owns one query column of the swapped score block, so the shift may depend on the lane's
         // query: s_ij <= |q^_i| max_j |k^_j|.  The norm is taken from the very fragments the MFMAs consume (this lane holds
@@ -287,7 +302,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
             const float* rs = reinterpret_cast<const float*>(p.est_ws) + (long)bh * p.Nq;
             const int r0 = q_base + frow;
             shift = rs[r0 < p.Nq ? r0 : p.Nq - 1] - EST_BIAS;
-            if constexpr (QB == 2) {
+            if constexpr (QB == 2 && EST_NODELTA) {
+                const int r1 = r0 + 32;
+                shift = fmaxf(shift, rs[r1 < p.Nq ? r1 : p.Nq - 1] - EST_BIAS);
+            } else if constexpr (QB == 2) {
                 // the lane's second row keeps ITS shift: the accumulator-input vector carries the first row's, the difference
                 // is subtracted from the second block's scores before the exponential (16 packed adds per 64-key tile).  A
                 // shared shift -- the larger of the two, as under the norm bound -- flushes the other row's numerators whenever
@@ -296,6 +314,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                 est_delta = rs[r1 < p.Nq ? r1 : p.Nq - 1] - EST_BIAS - shift;
             }
             shift -= (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
+            if constexpr (EST_CZERO) {   // both shifts go through the packed adds: block 0 subtracts shift, block 1 shift + delta
+                est_shift0 = shift;
+                shift = 0.f;
+            }
         } else {
             float n2 = 0.f;
 #pragma unroll
@@ -384,11 +406,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         float ls0 = 0.f, ls1 = 0.f, ls2 = 0.f, ls3 = 0.f;
 #pragma unroll
         for (int kvh = 0; kvh < 2; ++kvh) {
-            if (EST && QB == 2 && qb == 1) {
+            if ((EST && QB == 2 && qb == 1) || (EST && EST_CZERO)) {
                 // the accumulator holds s - c + SHIFT with c of the FIRST block's row: move to this row's shift, two scores per
                 // v_pk_add_f32 (written as scalar subtractions the compiler emitted 32 v_sub_f32 per tile)
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
-                const f32x2 d2 = {est_delta, est_delta};
+                const float dsub = EST_CZERO ? (qb == 1 ? est_shift0 + est_delta : est_shift0) : est_delta;
+                const f32x2 d2 = {dsub, dsub};
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     f32x2 t = {s[kvh][r], s[kvh][r + 1]};

@@ -64,6 +64,7 @@ def _segment_min(values: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
     return torch.segment_reduce(values, "min", lengths=counts, unsafe=True)
 
 
+LAST_STATS = {}   # reports: Boruvka rounds and component counts of the last mutual_reachability_mst call
 COMPONENT_BOUND = os.environ.get("IGGT_HDB_COMPONENT_BOUND", "1") != "0"   # A/B switch of the per-component pruning (csrc/hdbscan.hip)
 
 
@@ -88,6 +89,8 @@ def mutual_reachability_mst(x: torch.Tensor, min_samples: int, _kernels=None):
     big = float(2 ** 62)
     eu, ev, ew = [], [], []
     ncomp = M
+    LAST_STATS.clear()
+    LAST_STATS.update(points=M, components_per_round=[M])
     while ncomp > 1:
         comps, order = torch.sort(comp, stable=True)               # positions sorted by component, spatial order inside
         xs, c2s = x[order].contiguous(), core2[order].contiguous()
@@ -133,6 +136,7 @@ def mutual_reachability_mst(x: torch.Tensor, min_samples: int, _kernels=None):
         if n_new >= ncomp:
             raise _C.HipExtensionError("hdbscan: a Boruvka round merged nothing (non-finite features?)")
         ncomp = n_new
+        LAST_STATS["components_per_round"].append(n_new)
     eu, ev, ew = torch.cat(eu), torch.cat(ev), torch.cat(ew)
     if eu.numel() != M - 1:
         raise _C.HipExtensionError(f"hdbscan: spanning tree has {eu.numel()} edges for {M} points")

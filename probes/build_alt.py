@@ -14,6 +14,12 @@ VARIANTS = {
     "attn_nopin": {"attention_v3.hip": ["-DIGGT_ATTN_NO_PIN"]},
     "attn_nopin_noslp": {"attention_v3.hip": ["-DIGGT_ATTN_NO_PIN", "-fno-slp-vectorize"]},
     "hdb_stats": {"hdbscan.hip": ["-DIGGT_HDB_STATS"]},
+    # estimated-shift instantiation of the static attention kernel (round 4; timed by probes/attn_est_ab.py)
+    "est_default_sched": {"attention_v3_est.hip": []},
+    "est_czero": {"attention_v3_est.hip": ["-DIGGT_EST_CZERO"]},
+    "est_czero_maxilp": {"attention_v3_est.hip": ["-DIGGT_EST_CZERO", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]},
+    "est_nodelta_maxilp": {"attention_v3_est.hip": ["-DIGGT_EST_NODELTA", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]},
+    "est_nodelta": {"attention_v3_est.hip": ["-DIGGT_EST_NODELTA"]},
     # LLVM scheduling strategies on the three matrix-pipe kernels (timed by probes/sched_ab.py); iterative-ilp does not get
     # through attention_v3.hip (compiler error)
     **{f"sched_{n}": {f: fl for f in ("attention_v3.hip", "gemm_bf16_t256.hip", "conv3x3_halo.hip")}
@@ -27,7 +33,7 @@ def main():
     build_ext.build(verbose=False)
     out_dir = os.path.join(ROOT, "probes", "lib_alt")
     os.makedirs(out_dir, exist_ok=True)
-    names = sys.argv[1:] or [n for n in VARIANTS if not n.startswith("sched_")]
+    names = sys.argv[1:] or [n for n in VARIANTS if not n.startswith(("sched_", "est_"))]
     for name in names:
         objs, procs = [], []
         for src in build_ext.sources():

@@ -130,7 +130,7 @@ def test_prepass_table_is_min_of_norm_bound_and_sampled_maximum(C, kind):
     x = qkv.view(N, 3, H, 64).float()
     target = min(max(N // 64, 128), 512)
     stride = max(N // target, 1)
-    slack = float(min(max(15 - (math.ceil(math.log2(N)) - 13) - 1, 4), 12))
+    slack = float(min(max(math.floor(28 - math.log2(N) - math.log2(1.25)), 4), 12))
     for h in range(H):
         q, k = x[:, 0, h], x[:, 1, h]
         kn = k.norm(dim=-1)

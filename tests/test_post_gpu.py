@@ -215,6 +215,40 @@ def test_hdbscan_spanning_tree_and_labels_match_scikit_learn():
         assert got.max() == ref.max() and ari > 0.99, (name, ari)
 
 
+def test_hdbscan_on_model_features_at_the_demo_scale_matches_scikit_learn():
+    """Parity where the estimator is used (reference misc.py:123-129, demo.py:78-83,365-400): 169 344 pixels of the reference
+    model's L2-normalised `part_feat` on the demo7 photographs (4 views x 168 x 252, fixture oracle/make_golden_hdbscan.py),
+    the demo's parameters (min_samples 100, min_cluster_size 500, epsilon 0.06).  Oracle: scikit-learn's HDBSCAN (kd_tree, 204 s
+    on 8 host cores) -- 7 clusters, one of 148 448 pixels and six of 640 ... 994, 15 881 noise pixels.  The GPU estimator must
+    find the same partition (ARI >= 0.99, same cluster count; labels agree up to a permutation).  Time and the component count
+    after every Boruvka round go to the parity report; the 1.35 M-point timing is test_hdbscan_timing_report."""
+    import time
+
+    from sklearn.metrics import adjusted_rand_score
+
+    from conftest import load_golden, report
+    from iggt_official_amd.utils import hdbscan as hd
+
+    g = load_golden("hdbscan_demo7_part_feat")
+    x = g["features"].float().cuda()
+    ref = g["labels"].numpy()
+    kw = g["params"]
+    hd.hdbscan_labels(x[:20000], kw["min_cluster_size"], kw["min_samples"], kw["cluster_selection_epsilon"])   # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = hd.hdbscan_labels(x, kw["min_cluster_size"], kw["min_samples"], kw["cluster_selection_epsilon"])
+    dt = time.perf_counter() - t0
+    ari = adjusted_rand_score(ref, got)
+    both = (ref >= 0) & (got >= 0)
+    rep = dict(points=len(ref), clusters=int(got.max() + 1), clusters_ref=int(ref.max() + 1), ari=ari,
+               ari_on_pixels_both_label=adjusted_rand_score(ref[both], got[both]), noise=int((got < 0).sum()),
+               noise_ref=int((ref < 0).sum()), sizes=sorted(np.bincount(got[got >= 0]).tolist()),
+               sizes_ref=sorted(np.bincount(ref[ref >= 0]).tolist()), seconds=dt, seconds_sklearn=g["seconds_sklearn"],
+               boruvka_components_per_round=hd.LAST_STATS.get("components_per_round"))
+    report("post/hdbscan/demo7_part_feat_169k", rep)
+    assert got.max() == ref.max() and ari > 0.99, rep
+
+
 def test_hdbscan_component_bound_keeps_the_spanning_tree():
     """The per-component pruning of the Boruvka kernel (csrc/hdbscan.hip: workgroups inside one component share the best weight
     found so far) must not change a single edge: same (u, v, w) set with the bound on and off, on clustered and on uniform data,

@@ -102,13 +102,13 @@ def test_weight_beyond_fp16_range_without_a_fold_partner():
 def test_range_folding_keeps_fp16_operands_for_reparametrised_checkpoints():
     """The same function written with weight columns / rows of magnitude ~1e5 (a LayerNorm scale of 1e-5 in front of a 1e5
     qkv / fc1 column, a LayerScale of 1e-5 behind a 1e5 proj / fc2 row, a tiny V channel in front of a 1e5 proj column --
-    every place where a power of two moves between two partners exactly): the checkpoint does not fit fp16 as stored, range
+    every place where a power of two (here 2^22) moves between two partners exactly): the checkpoint does not fit fp16 as stored, range
     folding (layers/blocks.py fold_ranges) undoes the re-parametrisation at pack time, the trunk stays on fp16 operands, no
     16-bit store saturates and the outputs stay within 1e-3 of the CPU fp32 restatement run on the checkpoint AS STORED."""
     from iggt_official_amd import precision
     from oracle import restate, weights
 
-    K = 2.0 ** 17
+    K = 2.0 ** 22          # weights of ~0.05 become ~2e5: beyond the fp16 range
     model = build_gpu_model("stress", 0)
     images = _tiny_inputs()
     sd = weights.fill_state_dict(schema(), seed=0, mode="stress", device="cuda")
