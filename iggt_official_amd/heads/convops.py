@@ -183,6 +183,11 @@ def run(pc: PackedConv, x: torch.Tensor, *, out: Optional[torch.Tensor] = None, 
     flops = 2.0 * N * Ho * Wo * pc.Cout * pc.KH * pc.KW * pc.Cin
     if prec == 2 and flops < PREC2_MIN_FLOPS:
         prec = 3          # small problem: the two correction launches cost more than the third MFMA pass
+    if prec == 2 and (max(pc.pad_y, pc.pad_x) > pc.stride or pc.KH * pc.KW > 16 or pc.Cin > 8192 or pc.Cin % 8):
+        # geometries whose mean-input compensation has no nine-border-class description (csrc/conv_igemm.hip returns -6 for
+        # them at two passes): decided here, up front, so that a captured graph always holds the same kernels.  The stock DPT
+        # configuration never gets here; custom heads / strides may.
+        prec = 3
     w_a, w_b = pc.planes(prec)
     with profiling.region("conv", (flops, 2 if prec == 2 else 3)):    # (algorithmic FLOPs, MFMA passes per product)
         _C.conv2d_nhwc(x, w_a, w_b, pc.bias, out, KH=pc.KH, KW=pc.KW, stride=pc.stride, pad_y=pc.pad_y,

@@ -33,15 +33,22 @@ from .utils import pos_embed_map, pos_embed_rows
 def custom_interpolate(x, size=None, scale_factor=None, mode="bilinear", align_corners=True):
     """Reference dpt_head.py:484-509 (NCHW in, NCHW out) on the HIP resize kernel (csrc/dpt_tail.hip
     bilinear_ac_nhwc_kernel).  The reference only ever calls it as bilinear / align_corners=True; anything else raises --
-    there is no torch fallback in the product."""
+    there is no torch fallback in the product.  Any channel count (the kernel moves 8 channels per thread: other counts are
+    zero-padded for the call); returns a contiguous fp32 NCHW tensor without autograd history (inference path)."""
     if mode != "bilinear" or not align_corners:
         raise _C.HipExtensionError("custom_interpolate: only bilinear, align_corners=True is built (the reference's use)")
     if x.dim() != 4 or not x.is_cuda:
         raise _C.HipExtensionError("custom_interpolate expects a [N, C, H, W] tensor on the GPU (no CPU fallback)")
     if size is None:
+        if scale_factor is None:
+            raise ValueError("custom_interpolate: either size or scale_factor must be given")
         size = (int(x.shape[-2] * scale_factor), int(x.shape[-1] * scale_factor))
-    nhwc = x.detach().float().permute(0, 2, 3, 1).contiguous()
-    return co.resize(nhwc, tuple(int(v) for v in size)).permute(0, 3, 1, 2)
+    C = x.shape[1]
+    nhwc = x.detach().float().permute(0, 2, 3, 1)
+    if C % 8:
+        nhwc = torch.nn.functional.pad(nhwc, (0, 8 - C % 8))
+    out = co.resize(nhwc.contiguous(), tuple(int(v) for v in size))
+    return out[..., :C].permute(0, 3, 1, 2).contiguous()
 
 
 # FeatureFusionBlock: 1 x 1 out_conv before the upsampling instead of after it (exact identity, see forward_nhwc).

@@ -51,6 +51,8 @@ def spatial_order(x: torch.Tensor) -> torch.Tensor:
 
     finite = torch.nan_to_num(x, nan=0.0, posinf=0.0, neginf=0.0)
     p3 = _C.project3(finite, misc.pca_axes(finite, 3)) if C > 3 else finite.contiguous()
+    if C < 3:      # fewer than three feature channels: the Morton kernel reads x, y, z -- missing axes are constant zero
+        p3 = torch.cat([p3, p3.new_zeros(M, 3 - C)], 1)
     center = p3.mean(0)
     spread = float(p3.std(0).max())
     cell = max(6.0 * spread, 1e-30) / 1024.0

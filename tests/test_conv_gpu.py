@@ -433,3 +433,19 @@ def test_fusion_block_out_conv_before_resize_is_the_same_map():
     y = rcu(b.resConfUnit2, xd0 + rcu(b.resConfUnit1, xd1))
     ref = b.out_conv(F.interpolate(y, size=(37, 53), mode="bilinear", align_corners=True))
     assert _err(first.permute(0, 3, 1, 2), ref)[0] < 2e-5
+
+
+@pytest.mark.parametrize("C", [5, 8, 13])
+def test_custom_interpolate_any_channel_count(C):
+    """Reference dpt_head.py:484-509: a general bilinear / align_corners wrapper.  The HIP resize kernel moves 8 channels per
+    thread; other channel counts are zero-padded for the call, and the result is a contiguous fp32 NCHW tensor."""
+    from iggt_official_amd.heads.dpt_head import custom_interpolate
+
+    g = torch.Generator(device="cuda").manual_seed(C)
+    x = torch.randn(2, C, 19, 23, generator=g, device="cuda")
+    y = custom_interpolate(x, size=(37, 52))
+    ref = torch.nn.functional.interpolate(x.double(), size=(37, 52), mode="bilinear", align_corners=True)
+    assert y.shape == (2, C, 37, 52) and y.is_contiguous() and y.dtype == torch.float32
+    assert float((y.double() - ref).abs().max()) < 1e-5
+    y2 = custom_interpolate(x, scale_factor=2)
+    assert y2.shape == (2, C, 38, 46)
