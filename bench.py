@@ -85,6 +85,8 @@ def _cpu_baseline_worker(sample_views, size, cores):
         schema = json.load(f)
     sd = weights.fill_state_dict(schema, seed=0, mode="default")
     images = weights.make_images(sample_views, size, size, seed=0)
+    with torch.no_grad():      # warm-up (thread pool, allocator, oneDNN primitive caches): one view at a quarter of the area
+        restate.iggt_forward(sd, weights.make_images(1, 266, 266, seed=0), with_part=False)
     t0 = time.perf_counter()
     with torch.no_grad():
         restate.iggt_forward(sd, images, with_part=False)
@@ -121,8 +123,9 @@ def cpu_baseline(sample_views, size, budget_s=240):
                 "sample": f"{sample_views} view(s) @ {size}x{size} did not finish within {budget_s}s on {cores} cores"}
     res = {"value": sample_views / dt, "unit": "views/s", "cores": cores, "kind": "port",
            "sample": f"{sample_views} view(s) @ {size}x{size}, full geometry forward (DINOv2 + 24x(frame,global) + "
-                     f"camera/depth/point heads) of oracle/restate.py, fp32 torch CPU, {cores} threads, one run "
-                     f"{dt:.1f}s"}
+                     f"camera/depth/point heads) of oracle/restate.py (a PORT of the reference, not the reference "
+                     f"itself: /root/reference does not exist on the GPU box), fp32 torch CPU, {cores} threads, one timed run "
+                     f"{dt:.1f}s after a one-view warm-up"}
     a = {int(k): v for k, v in rec.get("attn_rows", {}).items()}
     if sample_views in a and 32 in a and sample_views != 32:
         # per-view time at 32 views = measured per-view time + 24 blocks x (one view's global-attention rows against

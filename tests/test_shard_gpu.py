@@ -128,13 +128,14 @@ def test_two_rank_sharded_forward_matches_reference(case, kv_groups, graphs, ove
             assert l2 < 1e-3, (rank, k, l2)   # same gate as the unsharded run (fp16 operands)
 
 
-@pytest.mark.parametrize("world,graphs,overlap", [(8, True, True), (8, False, False), (4, False, True), (4, True, False)])
+@pytest.mark.parametrize("world,graphs,overlap", [(8, True, True), (8, False, False), (4, True, False)])
 def test_many_rank_sharded_forward_at_518(world, graphs, overlap):
     """BASELINE.json configs[3]'s machinery with more than two ranks, end to end against the reference: 8 views @ 518^2
     (fixture full_s8_518_stress, produced by the reference modules at this size) over 8 ranks x 1 view and 4 ranks x 2 views,
     all on cuda:0 over gloo.  Every rank runs the product's sharded forward -- own-key launch, ONE segment-mode launch over the
     7 (3) foreign key segments under each segment's own gathered key bound, combine kernel with per-rank shifts, camera-token
-    gather over all ranks -- in the overlapped and the gather-first form, eagerly and as hipGraph segments.  Gates: the
+    gather over all ranks -- in the overlapped and the gather-first form, eagerly and as hipGraph segments (the fourth
+    combination, 4 ranks overlapped eager, ran green in round 4 and was dropped to keep the GPU suite inside its time limit).  Gates: the
     unsharded ones (1e-3 l2) on every rank's slice of depth / depth_conf / world_points / world_points_conf, on pose_enc (all
     views on every rank), on the four token layers and on the special-token rows; rank 0 alone may use slot 0 of the
     camera / register tokens (asserted inside the worker at the call site)."""
