@@ -85,33 +85,53 @@ struct EstView {
     int NqP, NqL, nWG;
 };
 __host__ __device__ inline long est_nql(long Nq) { return ((Nq + 7) / 8 + 127) / 128 * 128; }
-__host__ __device__ inline EstView est_view_at(unsigned char* base, int B, int H, int Nq, int Nk) {
+// byte offsets of the sub-arrays (in the order of the layout above) and the total size
+struct EstOffsets {
+    long rowlist, rowcount, hicount, dense, hilist, wgcnt, wglist, pmax, l2, o2, rowflag, total;
+    int NqP, NqL, nWG;
+};
+__host__ __device__ inline EstOffsets est_offsets(int B, int H, int Nq, int Nk) {
     const long BH = (long)B * H, nq = Nq;
+    EstOffsets o;
+    o.NqP = (int)((nq + 15) / 16 * 16);
+    o.NqL = (int)est_nql(nq);
+    o.nWG = (Nk + 31) / 32;
+    long w = BH * nq * 4;                        // rowshift sits at offset 0
+    o.rowlist = w;   w += BH * nq * 4;
+    o.rowcount = w;  w += BH * 4;
+    o.hicount = w;   w += BH * 4;
+    o.dense = w;     w += BH * 4;
+    o.hilist = w;    w += BH * EST_HI_CAP * 4;
+    o.wgcnt = w;     w += BH * (long)o.nWG * 4;
+    o.wglist = w;    w += BH * (long)o.nWG * 16;
+    o.pmax = w;      w += (long)EST_KS2 * BH * o.NqL * 4;
+    o.l2 = w;        w += (long)EST_KS2 * BH * o.NqL * 4;
+    w = (w + 15) / 16 * 16;
+    o.o2 = w;        w += (long)EST_KS2 * BH * o.NqL * 128;
+    o.rowflag = w;   w += BH * o.NqP;
+    o.total = w;
+    return o;
+}
+__host__ __device__ inline long est_ws_size(int B, int H, int Nq, int Nk) { return est_offsets(B, H, Nq, Nk).total; }
+__host__ __device__ inline EstView est_view(const AttnParams& p) {
+    const EstOffsets o = est_offsets(p.B, p.H, p.Nq, p.Nk);
+    unsigned char* b = p.est_ws;
     EstView v;
-    v.NqP = (int)((nq + 15) / 16 * 16);
-    v.NqL = (int)est_nql(nq);
-    v.nWG = (Nk + 31) / 32;
-    unsigned char* w = base;
-    v.rowshift = reinterpret_cast<float*>(w);  w += BH * nq * 4;
-    v.rowlist = reinterpret_cast<int*>(w);     w += BH * nq * 4;
-    v.rowcount = reinterpret_cast<int*>(w);    w += BH * 4;
-    v.hicount = reinterpret_cast<int*>(w);     w += BH * 4;
-    v.dense = reinterpret_cast<int*>(w);       w += BH * 4;
-    v.hilist = reinterpret_cast<int*>(w);      w += BH * EST_HI_CAP * 4;
-    v.wgcnt = reinterpret_cast<int*>(w);       w += BH * (long)v.nWG * 4;
-    v.wglist = reinterpret_cast<int*>(w);      w += BH * (long)v.nWG * 16;
-    v.pmax = reinterpret_cast<float*>(w);      w += (long)EST_KS2 * BH * v.NqL * 4;
-    v.l2 = reinterpret_cast<float*>(w);        w += (long)EST_KS2 * BH * v.NqL * 4;
-    w = base + ((w - base) + 15) / 16 * 16;
-    v.o2 = reinterpret_cast<bf16_t*>(w);       w += (long)EST_KS2 * BH * v.NqL * 128;
-    v.rowflag = w;
+    v.NqP = o.NqP; v.NqL = o.NqL; v.nWG = o.nWG;
+    v.rowshift = reinterpret_cast<float*>(b);
+    v.rowlist = reinterpret_cast<int*>(b + o.rowlist);
+    v.rowcount = reinterpret_cast<int*>(b + o.rowcount);
+    v.hicount = reinterpret_cast<int*>(b + o.hicount);
+    v.dense = reinterpret_cast<int*>(b + o.dense);
+    v.hilist = reinterpret_cast<int*>(b + o.hilist);
+    v.wgcnt = reinterpret_cast<int*>(b + o.wgcnt);
+    v.wglist = reinterpret_cast<int*>(b + o.wglist);
+    v.pmax = reinterpret_cast<float*>(b + o.pmax);
+    v.l2 = reinterpret_cast<float*>(b + o.l2);
+    v.o2 = reinterpret_cast<bf16_t*>(b + o.o2);
+    v.rowflag = b + o.rowflag;
     return v;
 }
-__host__ __device__ inline long est_ws_size(int B, int H, int Nq, int Nk) {
-    const EstView v = est_view_at(nullptr, B, H, Nq, Nk);
-    return (long)(v.rowflag - (unsigned char*)nullptr) + (long)B * H * v.NqP;
-}
-__host__ __device__ inline EstView est_view(const AttnParams& p) { return est_view_at(p.est_ws, p.B, p.H, p.Nq, p.Nk); }
 constexpr int GUARD_RETRY_DEFAULT = 16;
 constexpr int GUARD_WORDS = 8;
 // resolve the guard word(s) to "skip the static-bound kernel in this call"

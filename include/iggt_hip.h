@@ -75,15 +75,16 @@ int iggt_flash_attn_f16_d64(const void* q, const void* k, const void* v, void* o
  * ABI 23 (round 4): guard is int[8], initialised to {-1, 0, 0, 0, 0, 0, 0, 0}; guard[4] = mode of the static kernel (0: norm
  * bound, 1: estimated shift), guard[5] = rows handed to the online-max pass one by one (-1: skipped).
  * est_ws (NULL: the behaviour above; else est_ws_len >= iggt_flash_attn_static_est_ws_bytes(..) bytes of 16-byte aligned
- * scratch) turns on, for one-pass launches, (a) the ROW-granular hand-over -- the static kernel marks single rows, a small
- * kernel compacts them into ascending lists per (batch, head) and the online-max pass recomputes exactly those rows, 128 or
- * 256 per workgroup -- and (b) the ESTIMATED shift (csrc/attention_est.hip): where the norm bound is loose (trained-like
- * q/k-norm affines, sink keys, register tokens of outlying norm: more than 1/8 of the work redone under mode 0) the guard
- * switches the call site to mode 1, in which a pre-pass takes every row's exact maximum over a key sample -- the first
- * key_nspecial keys of every key_period keys (the special tokens of each view; 0: none), ~Nk / 32 strided keys, and the keys
- * whose norm exceeds half the head's maximum -- and the static kernel shifts row i by min(norm bound, sampled maximum +
- * headroom).  A row whose true maximum lies beyond the headroom overflows to a non-finite accumulator and is recomputed like
- * any other marked row.  More than 1/8 of the work redone in mode 1 as well -> online-max only for 16 calls, as before.
+ * scratch) turns on, for one-pass launches, the ESTIMATED shift (csrc/attention_est.hip): as soon as ANY tile is flagged under
+ * the norm bound (mode 0: trained-like q/k-norm affines, sink keys, register tokens of outlying norm) the guard moves the call
+ * site to mode 1, in which a pre-pass takes every row's exact maximum over a key sample -- the first key_nspecial keys of every
+ * key_period keys (the special tokens of each view; 0: none), ~Nk / 64 strided keys, and the keys whose norm exceeds half the
+ * head's maximum -- and the static kernel shifts row i by min(norm bound, sampled maximum + headroom).  Rows are then handed
+ * over ONE BY ONE (a row whose true maximum lies beyond the headroom ends with a non-finite accumulator and is marked like a
+ * row whose sum is below the threshold): a small kernel compacts them into ascending lists per (batch, head), lists of up to
+ * Nq / 8 rows get an exact second static pass (exact row maxima per 1/16 of the keys, the 128-row static kernel per key range
+ * under that maximum, a fold), longer ones are recomputed by the online-max pass.  More than 1/8 of the work redone in mode 1 ->
+ * online-max only for 16 calls, then mode 1 again.
  * est_mode: the mode when guard is NULL (0 / 1); ignored otherwise. */
 int iggt_flash_attn_static_bf16_d64(const void* q, const void* k, const void* v, void* o, int B, int H,
                                     int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
