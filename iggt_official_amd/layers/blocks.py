@@ -206,6 +206,11 @@ class Block(nn.Module):
         self.sample_drop_ratio = drop_path
         self._packed = None
         self._packed_key = None
+        # host-side switch of the estimated-shift launches of this block's attention (csrc/attention_est.hip): off until a
+        # snapshot of the guard word shows that the norm bound flagged tiles here (models/aggregator.py _apply_guard_snapshot).
+        # While it is off the block issues exactly the round-3 launch sequence: the nine extra launches of the estimated-shift
+        # sequence cost ~45 us per attention call even when every one of them returns at once (2 ms per 32-view forward).
+        self._est_on = False
 
     # ------------------------------------------------------------------------------------------
     def packed(self):
@@ -270,6 +275,7 @@ class Block(nn.Module):
                 # adaptive switch of the static-bound attention (include/iggt_hip.h): persistent per call site, reset with the
                 # packs (new weights -> new score statistics)
                 self._packed["guard"] = _C.new_attn_guard(dev)
+                self._est_on = False
             self._packed_key = key
         return self._packed
 
@@ -363,7 +369,7 @@ class Block(nn.Module):
                     nws = _C.static_attn_ws_bytes(batch, H, tokens, Nk) if q_rows_per_wg == 0 else 0
                     part_ws = ws.get("attn_part", (nws,), torch.uint8, dev) if nws else None
                     est_ws = None
-                    if guard is not None and not nws and precision.attn_estimated_shift():
+                    if guard is not None and not nws and self._est_on and precision.attn_estimated_shift():
                         est_ws = ws.get("attn_est", (_C.static_attn_est_ws_bytes(batch, H, tokens, Nk),), torch.uint8, dev)
                     # the estimated-shift pre-pass samples the special tokens of every view among the keys: the first
                     # `patch_start` rows of every P rows (frame attention: of the one view; global: of each view)

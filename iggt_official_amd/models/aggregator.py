@@ -65,6 +65,7 @@ class Aggregator(nn.Module):
         self.keep_layers = keep_layers
         self.shard: Optional[ViewShard] = None  # set by IGGT.set_view_shard for multi-GPU runs
         self._ws = Workspace()
+        self._guard_snap = None   # (pinned host copy of the 48 guard words, event) of the last eager forward
 
     def __build_patch_embed__(self, patch_embed, img_size, patch_size, num_register_tokens,
                               interpolate_antialias=True, interpolate_offset=0.0, block_chunks=0,
@@ -123,6 +124,7 @@ class Aggregator(nn.Module):
             cos, sin = self.rope.tables(self.frame_blocks[0].attn.head_dim, max(gh, gw), dev)
             rope_geom = dict(P=P, gw=gw, patch_start=psi, cos=cos, sin=sin)
         kv_gather = self.shard if (self.shard is not None and self.shard.active) else None
+        self._apply_guard_snapshot()
 
         x2d = tokens.view(T, C)
         keep = self._keep()
@@ -142,7 +144,57 @@ class Aggregator(nn.Module):
                     half = 0 if kind == "frame" else 1
                     cat[0, :, :, half * C:(half + 1) * C].copy_(tokens)
             out[i] = cat
+        self._begin_guard_snapshot()
         return out, psi
+
+    # ------------------------------------------------------------------------------------------
+    # Which blocks need the estimated-shift launches is decided on the device (the guard words), but WHETHER the launches are
+    # issued at all is a host decision -- and the host must not wait for the device.  So every eager forward ends with an
+    # asynchronous copy of the 48 guard words into pinned memory, and the next forward, if that copy has landed (event query,
+    # no wait), turns the launches on for the blocks whose norm-bound kernel flagged tiles or was skipped, and re-arms their
+    # guard in estimated mode.  Blocks on LayerNorm-of-noise statistics (every fixture, the bench) never pay for the machinery;
+    # a block that needs it runs one forward on the round-3 fallback first.  Under hipGraph replay nothing is re-decided: the
+    # two eager warm-up forwards in front of every capture (graphs.GraphCache.run) take the decision for the captured graph.
+    def _guards(self):
+        blocks = list(self.frame_blocks) + list(self.global_blocks)
+        return [(b, b.attn_guard()) for b in blocks if b.attn_guard() is not None]
+
+    def _begin_guard_snapshot(self):
+        from .. import precision
+
+        if not precision.attn_estimated_shift() or torch.cuda.is_current_stream_capturing():
+            return
+        gs = self._guards()
+        if not gs or all(b._est_on for b, _ in gs) or self._guard_snap is not None:   # (an older snapshot is still on its way)
+            return
+        host = getattr(self, "_guard_host", None)
+        if host is None or host.shape[0] != len(gs):
+            host = self._guard_host = torch.empty(len(gs), _C.GUARD_WORDS, dtype=torch.int32, pin_memory=True)
+        host.copy_(torch.stack([g for _, g in gs]), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._guard_snap = (host, ev, [b for b, _ in gs], [g for _, g in gs])
+
+    def _apply_guard_snapshot(self):
+        snap, self._guard_snap = self._guard_snap, None
+        if snap is None or torch.cuda.is_current_stream_capturing():
+            self._guard_snap = snap
+            return
+        host, ev, blocks, guards = snap
+        if not ev.query():          # not there yet (the host runs ahead of the device): keep it for the next forward
+            self._guard_snap = snap
+            return
+        changed = False
+        for i, (b, g) in enumerate(zip(blocks, guards)):
+            flagged_or_skipped = int(host[i, 1]) != 0
+            if flagged_or_skipped and not b._est_on and b.attn_guard() is g:
+                b._est_on = True
+                g.copy_(torch.tensor([0, 0, 0, 0, 1, 0, 0, 0], dtype=torch.int32), non_blocking=True)   # estimated mode, armed
+                changed = True
+        if changed:
+            from .. import graphs
+
+            graphs.buffers_changed()    # captured graphs do not hold the estimated-shift launches of these blocks: re-capture
 
     def static_softmax_stats(self) -> dict:
         """Adaptive-switch words of the 48 aggregator blocks after a forward (synchronises): per kind, the number of query
