@@ -55,6 +55,7 @@ def main():
         eu, ev, ew, core = hd.mutual_reachability_mst(px, 100)
         torch.cuda.synchronize()
         res["hdbscan_core_and_spanning_tree_s"] = time.perf_counter() - t
+        res["hdbscan_boruvka_components_per_round"] = hd.LAST_STATS.get("components_per_round")
         t = time.perf_counter()
         labels = _C.hdbscan_labels_from_mst(eu.cpu().numpy(), ev.cpu().numpy(), ew.cpu().numpy(), M, 500, 0.06, False)
         res["hdbscan_tree_walk_host_s"] = time.perf_counter() - t
