@@ -535,7 +535,7 @@ def main():
                          "traffic": traffic.get("bytes_per_launch"),
                          "traffic_note": traffic.get("note", "no rocprofv3 PMC pass recorded for this kernel / shape "
                                                              "(profiles/attn_traffic.json)"),
-                         "algorithmic_bytes_per_launch": 4.0 * Nk * C * 2,
+                         "algorithmic_bytes_per_launch": 2.0 * (Nq + Nk) * C * 2,   # Q + O rows of this rank, K + V of all views
                          "launches_timed": len(recs), "ms_per_launch": ms,
                          "timing_note": ("HIP events around the launches of one eager forward right after the timed region "
                                          "(the timed steps replay hipGraph segments)") if graphs else
