@@ -303,11 +303,15 @@ def static_attn_est_views(est_ws, B, H, Nq, Nk=None):
     v = dict(rowshift=take(BH * Nq * 4).view(torch.float32).view(BH, Nq), rowlist=take(BH * Nq * 4).view(torch.int32).view(BH, Nq),
              rowcount=take(BH * 4).view(torch.int32), hicount=take(BH * 4).view(torch.int32), dense=take(BH * 4).view(torch.int32),
              hilist=take(BH * EST_HI_CAP * 4).view(torch.int32).view(BH, EST_HI_CAP))
-    take(BH * nWG * 4), take(BH * nWG * 16), take(EST_KS2 * BH * NqL * 4), take(EST_KS2 * BH * NqL * 4)
+    take(BH * nWG * 4), take(BH * nWG * 16)
+    NqS = (Nq + 255) // 256 * 256
+    v["slotrow"] = take(BH * NqS * 4).view(torch.int32).view(BH, NqS)
+    take(EST_KS2 * BH * NqL * 4), take(EST_KS2 * BH * NqL * 4)
     off[0] = (off[0] + 15) // 16 * 16
     take(EST_KS2 * BH * NqL * 128)
     v["rowflag"] = take(BH * NqP).view(BH, NqP)
     v["NqL"] = NqL
+    v["bytes"] = off[0]
     return v
 
 

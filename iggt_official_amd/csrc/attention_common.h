@@ -66,6 +66,8 @@ constexpr float EST_BIAS = 1048576.f;   // rowshift is stored + 2^20 (resolution
 //   hicount  i32 [BH], hilist i32 [BH][EST_HI_CAP]   keys of outlying norm (hicount > EST_HI_CAP: not an outlier set, ignored)
 //   dense    i32 [BH]       set by a key-scan workgroup that saw > 4 such keys among its 32 rows
 //   wgcnt    i32 [BH][nWG], wglist i32 [BH][nWG][4]    per-workgroup finds of the key scan (no atomics), compacted into hilist
+//   slotrow  i32 [BH][NqS]  (NqS = Nq rounded up to 256) the rows of every 256-row query tile in the order the 256-row static
+//            kernel deals them to its lanes: sorted by shift, so that the two rows a lane owns are neighbours in that order
 //   pmax     f32 [EST_KS2][BH][NqL]                    second chance: exact row maxima per key range
 //   l2       f32 [EST_KS2][BH][NqL], o2 16-bit [EST_KS2][BH][NqL][64]   second chance: partial row sums / outputs
 //   rowflag  u8  [BH][NqP]  (16-byte aligned) 1 = row handed over
@@ -78,17 +80,18 @@ struct EstView {
     int* hilist;
     int* wgcnt;
     int* wglist;
+    int* slotrow;
     float* pmax;
     float* l2;
     bf16_t* o2;
     unsigned char* rowflag;
-    int NqP, NqL, nWG;
+    int NqP, NqL, nWG, NqS;
 };
 __host__ __device__ inline long est_nql(long Nq) { return ((Nq + 7) / 8 + 127) / 128 * 128; }
 // byte offsets of the sub-arrays (in the order of the layout above) and the total size
 struct EstOffsets {
-    long rowlist, rowcount, hicount, dense, hilist, wgcnt, wglist, pmax, l2, o2, rowflag, total;
-    int NqP, NqL, nWG;
+    long rowlist, rowcount, hicount, dense, hilist, wgcnt, wglist, slotrow, pmax, l2, o2, rowflag, total;
+    int NqP, NqL, nWG, NqS;
 };
 __host__ __device__ inline EstOffsets est_offsets(int B, int H, int Nq, int Nk) {
     const long BH = (long)B * H, nq = Nq;
@@ -96,6 +99,7 @@ __host__ __device__ inline EstOffsets est_offsets(int B, int H, int Nq, int Nk) 
     o.NqP = (int)((nq + 15) / 16 * 16);
     o.NqL = (int)est_nql(nq);
     o.nWG = (Nk + 31) / 32;
+    o.NqS = (int)((nq + 255) / 256 * 256);
     long w = BH * nq * 4;                        // rowshift sits at offset 0
     o.rowlist = w;   w += BH * nq * 4;
     o.rowcount = w;  w += BH * 4;
@@ -104,6 +108,7 @@ __host__ __device__ inline EstOffsets est_offsets(int B, int H, int Nq, int Nk) 
     o.hilist = w;    w += BH * EST_HI_CAP * 4;
     o.wgcnt = w;     w += BH * (long)o.nWG * 4;
     o.wglist = w;    w += BH * (long)o.nWG * 16;
+    o.slotrow = w;   w += BH * (long)o.NqS * 4;
     o.pmax = w;      w += (long)EST_KS2 * BH * o.NqL * 4;
     o.l2 = w;        w += (long)EST_KS2 * BH * o.NqL * 4;
     w = (w + 15) / 16 * 16;
@@ -117,7 +122,7 @@ __host__ __device__ inline EstView est_view(const AttnParams& p) {
     const EstOffsets o = est_offsets(p.B, p.H, p.Nq, p.Nk);
     unsigned char* b = p.est_ws;
     EstView v;
-    v.NqP = o.NqP; v.NqL = o.NqL; v.nWG = o.nWG;
+    v.NqP = o.NqP; v.NqL = o.NqL; v.nWG = o.nWG; v.NqS = o.NqS;
     v.rowshift = reinterpret_cast<float*>(b);
     v.rowlist = reinterpret_cast<int*>(b + o.rowlist);
     v.rowcount = reinterpret_cast<int*>(b + o.rowcount);
@@ -126,6 +131,7 @@ __host__ __device__ inline EstView est_view(const AttnParams& p) {
     v.hilist = reinterpret_cast<int*>(b + o.hilist);
     v.wgcnt = reinterpret_cast<int*>(b + o.wgcnt);
     v.wglist = reinterpret_cast<int*>(b + o.wglist);
+    v.slotrow = reinterpret_cast<int*>(b + o.slotrow);
     v.pmax = reinterpret_cast<float*>(b + o.pmax);
     v.l2 = reinterpret_cast<float*>(b + o.l2);
     v.o2 = reinterpret_cast<bf16_t*>(b + o.o2);

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void attn_rowshift_kernel(const AttnParams p, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, fhalf = lane >> 5;
-    int work = xcd_remap(blockIdx.x, gridDim.x), ks = 0;
+    // (MODE 1 is a sparse launch whose rows concentrate on few heads: launch order, not the XCD-chunked one -- attention_v3.hip)
+    int work = MODE == 1 ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x), ks = 0;
     if (MODE == 1) {
         ks = work % EST_KS2;
         work /= EST_KS2;
@@ -276,6 +277,9 @@ __global__ __launch_bounds__(256) void attn_rowshift_kernel(const AttnParams p, 
         if (t + 1 < NT) step(t + 1, st[1]);
         if (t + 2 < NT) step(t + 2, st[2]);
     }
+    float* skey = reinterpret_cast<float*>(smem);          // MODE 0: the staging buffers become the sort's key / value arrays
+    int* sval = reinterpret_cast<int*>(smem + 1024);
+    if (MODE == 0) __syncthreads();
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const float mx = fmaxf(m[qb], __shfl_xor(m[qb], 32, 64));   // the two lane halves hold different keys of the same row
@@ -296,8 +300,39 @@ __global__ __launch_bounds__(256) void attn_rowshift_kernel(const AttnParams p, 
         }
         a2 += __shfl_xor(a2, 32, 64);
         const float cs = sqrtf(a2) * p.qkmax[16 + h] * 1.00002f + 1e-3f;   // the norm bound of attention_v3.hip, same rounding slack
-        if (fhalf == 0 && qr < p.Nq) ev.rowshift[(long)bh * p.Nq + qr] = fminf(cs, mx + slack) + EST_BIAS;
+        const float sh = fminf(cs, mx + slack);
+        if (fhalf == 0) {
+            if (qr < p.Nq) ev.rowshift[(long)bh * p.Nq + qr] = sh + EST_BIAS;
+            const int li = wave * 64 + qb * 32 + frow;
+            skey[li] = qr < p.Nq ? sh : INFINITY;                           // rows past the end sort last
+            sval[li] = qr;
+        }
     }
+    if (MODE == 1) return;
+    // The 256-row static kernel gives each lane TWO rows (query blocks 0 and 1) and applies the second row's own shift by 16
+    // packed adds per key tile -- 0.3 ms per launch at N = 43 968.  Waves whose 32 row pairs all agree to within half a bit skip
+    // those adds (a second copy of the tile loop, chosen per wave), so the rows of the tile are dealt to the lanes in the order
+    // of their shift: slot (wave w, block qb, lane row f) gets sorted entry 2 (32 w + f) + qb.  Where shifts vary smoothly over
+    // the rows (trained-like affines: 0.1 bit between neighbours of the order) nearly every wave qualifies; where a few sink
+    // keys spread them over hundreds of bits, none does and nothing is lost.
+    __syncthreads();
+    for (int k = 2; k <= 256; k <<= 1) {        // bitonic sort of the tile's 256 (shift, row) pairs, ascending; ties by row
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            const int partner = tid ^ jj;
+            if (partner > tid) {
+                const float a = skey[tid], bk = skey[partner];
+                const int av = sval[tid], bv = sval[partner];
+                const bool up = (tid & k) == 0;
+                const bool gt = a > bk || (a == bk && av > bv);
+                if (gt == up) {
+                    skey[tid] = bk; skey[partner] = a;
+                    sval[tid] = bv; sval[partner] = av;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    ev.slotrow[(long)bh * ev.NqS + qt * 256 + tid] = sval[2 * (32 * (tid >> 6) + (tid & 31)) + ((tid >> 5) & 1)];
 }
 
 // grid B * H, 256 threads: ascending list of the flagged rows of one (batch, head); 4 096 flag bytes per round

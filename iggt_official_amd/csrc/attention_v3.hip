@@ -46,6 +46,8 @@
 // with numerators in fp16's subnormal range.  Such rows are detected after the loop by their row sum
 // (l_i < Nk * 2^-13, attention_common.h) and their 256-row tile is flagged; the dynamic kernel (same file, gated on the flag
 // array) then recomputes exactly the flagged tiles.  With LayerNorm-ed q, k the slack is ~5 bits of the 29 available.
+#include <type_traits>
+
 #include "attention_common.h"
 #include "../../include/iggt_hip.h"
 
@@ -55,14 +57,9 @@ namespace {
 
 constexpr float DEFER_THR = 4.0f;  // log2 units: P <= 16
 
-// A/B builds of the estimated-shift instantiation (probes/build_alt.py est_*): IGGT_EST_CZERO applies BOTH query blocks' shifts
-// by packed adds in front of the exponentials and feeds the score MFMAs a zero accumulator (no 16-register shift vector);
-// IGGT_EST_NODELTA gives a lane's two rows one shared shift (the larger), as under the norm bound.
-#ifdef IGGT_EST_CZERO
-constexpr bool EST_CZERO = true;
-#else
-constexpr bool EST_CZERO = false;
-#endif
+// A/B build of the estimated-shift instantiation (probes/build_alt.py est_nodelta): IGGT_EST_NODELTA gives a lane's two rows
+// one shared shift (the larger), as under the norm bound.  (A second variant -- zero accumulator input, both blocks' shifts by
+// packed adds -- measured 8.12-8.15 ms against 7.87 and was removed: profiles/r04_attn_est_ab.txt)
 #ifdef IGGT_EST_NODELTA
 constexpr bool EST_NODELTA = true;
 #else
@@ -153,7 +150,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, fhalf = lane >> 5;
 
-    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    // LIST launches are sparse -- most workgroups find nothing to do -- and the rows that are there concentrate on few heads
+    // (measured: 3 575 of 5 888 listed rows in ONE head): under the XCD-chunked order all of that head's work items sit in one
+    // XCD's contiguous share of the list and run on its 32 CUs alone (7 rounds, 369 us); in launch order they spread over the chip
+    const int work = LIST ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     // online-max pass in LIST mode (round 4): the work item recomputes rows [qt * 128 QB, ...) of the (batch, head)'s list of
     // flagged rows (attention_est.hip attn_rowlist_kernel) instead of a contiguous query tile
     int nlist = -1;
@@ -214,6 +214,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         int qr = q_base + qb * 32 + frow;
+        if constexpr (EST && QB == 2) {   // the tile's rows are dealt to the lanes in the order of their shift (attention_est.hip)
+            const EstView ev = est_view(p);
+            qr = ev.slotrow[(long)bh * ev.NqS + qr];
+        }
         qr = qr < p.Nq ? qr : p.Nq - 1;
         if constexpr (!STATIC || LIST) {
             if (rlist != nullptr) qr = rlist[q_base + qb * 32 + frow < nlist ? q_base + qb * 32 + frow : nlist - 1];
@@ -283,7 +287,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
     // static bound: the (negated) shift enters through the accumulator input of the first QK^T MFMA of a score block
     f32x16 cinit;
     float est_delta = 0.f;   // EST, QB = 2: shift of the lane's second row minus that of its first
-    float est_shift0 = 0.f;  // EST_CZERO builds: the first row's shift (the accumulator input stays zero)
     if constexpr (STATIC) {
         // PER-ROW bound: a lane owns one query column of the swapped score block, so the shift may depend on the lane's
         // query: s_ij <= |q^_i| max_j |k^_j|.  The norm is taken from the very fragments the MFMAs consume (this lane holds
@@ -300,24 +303,24 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
             shift += 1.0f - (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
         } else if constexpr (EST) {   // min(norm bound, sampled row maximum + headroom) per row, from the pre-pass
             const float* rs = reinterpret_cast<const float*>(p.est_ws) + (long)bh * p.Nq;
-            const int r0 = q_base + frow;
-            shift = rs[r0 < p.Nq ? r0 : p.Nq - 1] - EST_BIAS;
-            if constexpr (QB == 2 && EST_NODELTA) {
-                const int r1 = r0 + 32;
-                shift = fmaxf(shift, rs[r1 < p.Nq ? r1 : p.Nq - 1] - EST_BIAS);
-            } else if constexpr (QB == 2) {
-                // the lane's second row keeps ITS shift: the accumulator-input vector carries the first row's, the difference
-                // is subtracted from the second block's scores before the exponential (16 packed adds per 64-key tile).  A
-                // shared shift -- the larger of the two, as under the norm bound -- flushes the other row's numerators whenever
-                // the two differ by more than a few bits: 38 % of the rows of the "sinks" regime were handed over for that
-                const int r1 = r0 + 32;
-                est_delta = rs[r1 < p.Nq ? r1 : p.Nq - 1] - EST_BIAS - shift;
+            if constexpr (QB == 2) {
+                // each of the lane's two rows keeps ITS shift: the accumulator-input vector carries the first row's, the
+                // difference is subtracted from the second block's scores before the exponential (16 packed adds per 64-key
+                // tile; tile_loop below).  A shared shift -- the larger of the two, as under the norm bound -- flushes the other
+                // row's numerators whenever the two differ by more than a few bits: 38 % of the rows of the "sinks" regime were
+                // handed over for that
+                const EstView ev = est_view(p);
+                const int* sr = ev.slotrow + (long)bh * ev.NqS + q_base + frow;
+                const int r0 = sr[0], r1 = sr[32];
+                shift = rs[r0 < p.Nq ? r0 : p.Nq - 1] - EST_BIAS;
+                const float sh1 = rs[r1 < p.Nq ? r1 : p.Nq - 1] - EST_BIAS;
+                if constexpr (EST_NODELTA) shift = fmaxf(shift, sh1);
+                else est_delta = sh1 - shift;
+            } else {
+                const int r0 = q_base + frow;
+                shift = rs[r0 < p.Nq ? r0 : p.Nq - 1] - EST_BIAS;
             }
             shift -= (FMT == FMT_F16 ? STATIC_SHIFT_F16 : 0.f);
-            if constexpr (EST_CZERO) {   // both shifts go through the packed adds: block 0 subtracts shift, block 1 shift + delta
-                est_shift0 = shift;
-                shift = 0.f;
-            }
         } else {
             float n2 = 0.f;
 #pragma unroll
@@ -401,17 +404,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                 for (int r = 0; r < 16; ++r) o[qb][dh][r] *= alpha;
         }
     };
-    auto exp_pack = [&](int qb, f32x16 (&s)[2], bf16x8 (&pf)[2][2]) {
+    auto exp_pack = [&](int qb, f32x16 (&s)[2], bf16x8 (&pf)[2][2], auto use_delta) {
         const float m = m_run[qb] - (FMT == FMT_F16 ? P_SHIFT_F16 : 0.f);
         float ls0 = 0.f, ls1 = 0.f, ls2 = 0.f, ls3 = 0.f;
 #pragma unroll
         for (int kvh = 0; kvh < 2; ++kvh) {
-            if ((EST && QB == 2 && qb == 1) || (EST && EST_CZERO)) {
+            if (decltype(use_delta)::value && qb == 1) {
                 // the accumulator holds s - c + SHIFT with c of the FIRST block's row: move to this row's shift, two scores per
                 // v_pk_add_f32 (written as scalar subtractions the compiler emitted 32 v_sub_f32 per tile)
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
-                const float dsub = EST_CZERO ? (qb == 1 ? est_shift0 + est_delta : est_shift0) : est_delta;
-                const f32x2 d2 = {dsub, dsub};
+                const f32x2 d2 = {est_delta, est_delta};
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     f32x2 t = {s[kvh][r], s[kvh][r + 1]};
@@ -480,44 +482,59 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
             NMT = (int)((long)(ks + 1) * NMT_all / p.ksplit);
         }
     }
-    dma(mt0, mt0 & 1);
-    __syncthreads();  // vmcnt(0) + barrier: first macro tile resident
-    for (int mt = mt0; mt < NMT; ++mt) {
-        if (mt + 1 < NMT) dma(mt + 1, (mt + 1) & 1);
-#pragma unroll
-        for (int sub = 0; sub < KVM; ++sub) {
-            const int t = mt * KVM + sub;
-            if (t < NT) {
-                const char* sK = smem + (mt & 1) * (KVM * BUF_BYTES) + sub * BUF_BYTES;
-                const char* sV = sK + K_BYTES;
-                const bool tail = (t + 1) * KV_TILE > nk;
-                f32x16 s0[2], s1[2];
-                bf16x8 pf0[2][2], pf1[2][2];
-                qk(sK, 0, s0);
-                if (tail) mask_tail(t, s0);
-                if constexpr (!STATIC) update_max(0, s0);
-                if constexpr (QB == 2) {
-                    qk(sK, 1, s1);
-                    exp_pack(0, s0, pf0);
-                    if constexpr (PIN) pin(pf0);
-                    if (tail) mask_tail(t, s1);
-                    if constexpr (!STATIC) update_max(1, s1);
-                    pv(sV, 0, pf0);
-                    exp_pack(1, s1, pf1);
-                    pv(sV, 1, pf1);
-                } else {
-                    exp_pack(0, s0, pf0);
-                    pv(sV, 0, pf0);
+    // the tile loop, in two copies for the estimated-shift kernel: with and without the second block's shift correction
+    auto tile_loop = [&](auto use_delta) {
+        dma(mt0, mt0 & 1);
+        __syncthreads();  // vmcnt(0) + barrier: first macro tile resident
+        for (int mt = mt0; mt < NMT; ++mt) {
+            if (mt + 1 < NMT) dma(mt + 1, (mt + 1) & 1);
+    #pragma unroll
+            for (int sub = 0; sub < KVM; ++sub) {
+                const int t = mt * KVM + sub;
+                if (t < NT) {
+                    const char* sK = smem + (mt & 1) * (KVM * BUF_BYTES) + sub * BUF_BYTES;
+                    const char* sV = sK + K_BYTES;
+                    const bool tail = (t + 1) * KV_TILE > nk;
+                    f32x16 s0[2], s1[2];
+                    bf16x8 pf0[2][2], pf1[2][2];
+                    qk(sK, 0, s0);
+                    if (tail) mask_tail(t, s0);
+                    if constexpr (!STATIC) update_max(0, s0);
+                    if constexpr (QB == 2) {
+                        qk(sK, 1, s1);
+                        exp_pack(0, s0, pf0, use_delta);
+                        if constexpr (PIN) pin(pf0);
+                        if (tail) mask_tail(t, s1);
+                        if constexpr (!STATIC) update_max(1, s1);
+                        pv(sV, 0, pf0);
+                        exp_pack(1, s1, pf1, use_delta);
+                        pv(sV, 1, pf1);
+                    } else {
+                        exp_pack(0, s0, pf0, use_delta);
+                        pv(sV, 0, pf0);
+                    }
                 }
             }
+            __syncthreads();  // everyone done with buffer mt&1; DMA of macro tile mt+1 landed
         }
-        __syncthreads();  // everyone done with buffer mt&1; DMA of macro tile mt+1 landed
+    };
+    if constexpr (EST && QB == 2 && !EST_NODELTA) {
+        // per wave: only if some lane's two rows differ by more than half a bit (the pre-pass dealt the rows in shift order, so
+        // neighbours rarely do); half a bit keeps the uncorrected row's largest numerator above the acceptance threshold
+        if (__any(fabsf(est_delta) > 0.5f)) tile_loop(std::true_type{});
+        else tile_loop(std::false_type{});
+    } else {
+        tile_loop(std::false_type{});
     }
 
     bool weak = false;   // static bound only: some row's numerators sank towards the subnormal range
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         int qr = q_base + qb * 32 + frow;
+        if constexpr (EST && QB == 2) {
+            const EstView ev = est_view(p);
+            qr = ev.slotrow[(long)bh * ev.NqS + qr];    // re-read: nothing extra stays alive across the tile loop
+        }
         const float l = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
         const float inv = (PART && !(l > 0.f)) ? 0.f : 1.0f / l;
         if constexpr (STATIC && !PART) {
@@ -628,8 +645,10 @@ static void launch_v3(const AttnParams& p_in, int q_rows, int kvm, hipStream_t s
     if (q_rows == 256) {
         p.qtiles = (p.Nq + 255) / 256;
         const dim3 grid(p.B * p.H * p.qtiles * mult), block(256);
-        if (kvm == 2) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2, FMT, STATIC, PIN_DEFAULT, PART, EST>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 1, FMT, STATIC, PIN_DEFAULT, PART, EST>), grid, block, 0, stream, p);
+        // (the estimated-shift kernel exists with 128-key macro tiles only at 256 rows: its two copies of the tile loop leave the
+        // 64-key variant 9-14 VGPRs short, spilled inside the loop)
+        if (kvm == 2 || EST) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 2, FMT, STATIC, PIN_DEFAULT, PART, EST>), grid, block, 0, stream, p);
+        else if constexpr (!EST) hipLaunchKernelGGL((flash_attn_d64_v3_kernel<2, 1, FMT, STATIC, PIN_DEFAULT, PART, EST>), grid, block, 0, stream, p);
     } else {
         p.qtiles = (p.Nq + 127) / 128;
         const dim3 grid(p.B * p.H * p.qtiles * mult), block(256);

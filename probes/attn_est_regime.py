@@ -13,7 +13,13 @@ from iggt_official_amd import _C  # noqa: E402
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "registers"
 H, C, P, T = r.H, r.C, r.P, r.T
-qkv, qkmax = r.make(kind, torch.float16)
+if kind.startswith("fewrows"):
+    # LayerNorm-of-noise operands with the first `n` query rows at 30x norm: n x 16 rows end up on the lists, nothing else
+    n = int(kind[7:] or 5)
+    qkv, qkmax = r.make("noise", torch.float16)
+    qkv.view(T, 3, H, 64)[:n, 0] *= 30.0
+else:
+    qkv, qkmax = r.make(kind, torch.float16)
 o = torch.empty(T, C, dtype=torch.float16, device="cuda")
 flags = torch.zeros(H * ((T + 127) // 128), dtype=torch.int32, device="cuda")
 args = (qkv, qkv[:, C:], qkv[:, 2 * C:], o, 1, H, T, T, 0, 3 * C, 0, 3 * C, 0, 3 * C, 0, C)

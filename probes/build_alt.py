@@ -16,8 +16,6 @@ VARIANTS = {
     "hdb_stats": {"hdbscan.hip": ["-DIGGT_HDB_STATS"]},
     # estimated-shift instantiation of the static attention kernel (round 4; timed by probes/attn_est_ab.py)
     "est_default_sched": {"attention_v3_est.hip": []},
-    "est_czero": {"attention_v3_est.hip": ["-DIGGT_EST_CZERO"]},
-    "est_czero_maxilp": {"attention_v3_est.hip": ["-DIGGT_EST_CZERO", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]},
     "est_nodelta_maxilp": {"attention_v3_est.hip": ["-DIGGT_EST_NODELTA", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]},
     "est_nodelta": {"attention_v3_est.hip": ["-DIGGT_EST_NODELTA"]},
     # LLVM scheduling strategies on the three matrix-pipe kernels (timed by probes/sched_ab.py); iterative-ilp does not get

@@ -152,6 +152,15 @@ def test_prepass_table_is_min_of_norm_bound_and_sampled_maximum(C, kind):
         true_max = (q @ k.t()).amax(dim=1)
         if kind == "sinks":      # every sink is in the sample: (almost) no numerator 2^(s - shift + 15) leaves the fp16 range
             assert float((got < true_max - 1.0).float().mean()) < 0.05
+        # slot table of the 256-row kernel: per tile a permutation of its rows (rows past the end last) that pairs neighbours
+        # of the shift order in one lane -- slot (wave w, block qb, lane row f) holds sorted entry 2 (32 w + f) + qb
+        slots = v["slotrow"][h].view(-1, 4, 2, 32)                     # [tile, wave, qb, frow]
+        order = slots.permute(0, 1, 3, 2).reshape(-1, 256)             # entry index 2 (32 w + f) + qb
+        ntile = order.shape[0]
+        assert torch.equal(order.sort(dim=1).values,
+                           torch.arange(ntile * 256, device="cuda", dtype=torch.int32).view(ntile, 256))
+        sh = torch.cat([v["rowshift"][h], torch.full((ntile * 256 - N,), float("inf"), device="cuda")])[order.long()]
+        assert bool((sh[:, 1:] >= sh[:, :-1]).all())
 
 
 def test_adaptive_switch_walks_norm_bound_estimated_online(C):
