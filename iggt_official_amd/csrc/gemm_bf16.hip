@@ -365,31 +365,22 @@ static int gemm_h16(int fmt, const void* A, long lda, const void* W, long ldw, i
     const long duo_tiles = (long)((M + 255) / 256) * (N / 128);
     // (at 8 / 16 views -- M = 10 992 / 21 984 -- the 256^2 tile wins on every shape again: fc2 740 vs 593, fc1 636 vs 576 TF/s)
     const bool duo_auto = duo == 2 && M >= 1024 && M < 8192 && duo_tiles <= 1024 && (big_tiles >= 128 || K >= 2048);
-    // Round 4 -- a ragged last row tile that costs a whole extra round of workgroups: the qkv GEMM of one rank of an 8-GPU run
-    // (M = 5 496 = 21 x 256 + 120, N = 3 072) is 22 x 24 = 528 tiles for 512 workgroup slots -- 16 tiles, all of them 47 % full,
-    // pay for a second round (70 us against ~36 us for one).  The full row tiles (21 x 24 = 504: one round) go to the duo kernel
-    // and the last 120 rows to the 128^2 kernel (24 tiles, ~8 us): disjoint output rows, same arithmetic per row.
-    // IGGT_GEMM_SPLIT_TAIL=0: one launch.
-    static int split_tail = -1;
-    if (split_tail < 0) {
-        const char* e = getenv("IGGT_GEMM_SPLIT_TAIL");
-        split_tail = (e && e[0] == '0') ? 0 : 1;
+    // Round 4 -- 192-row tiles where they need fewer rounds x rows of the 512 workgroup slots than 256-row ones
+    // (gemm_bf16_duo.hip).  M = 5 496, one rank of an 8-GPU run (probes/gemm_rank_ab.py, profiles/r04_gemm_rank_ab.txt):
+    // fc2 176 -> 232 workgroups of 3/4 the length, 76.2 -> 67.2 us; qkv 528 (two rounds, the second 3 % full) -> 696, 66.0 ->
+    // 58.4 us; fc1 704 -> 928, 81.6 -> 81.4 us (no gain: its rounds are the GELU epilogue's).  IGGT_GEMM_DUO192=0: 256 rows always.
+    static int duo192 = -1;
+    if (duo192 < 0) {
+        const char* e = getenv("IGGT_GEMM_DUO192");
+        duo192 = (e && e[0] == '0') ? 0 : 1;
     }
-    if (split_tail && duo_auto && rows_in == 0 && (N % 128) == 0 && force_small_tile() == 0) {
-        const int rem = M % 256, slots = 512;
-        const long full_tiles = (long)(M / 256) * (N / 128);
-        if (rem > 0 && rem <= 128 && full_tiles > 0 && (duo_tiles + slots - 1) / slots > (full_tiles + slots - 1) / slots) {
-            const int m1 = M - rem;
-            const long esz = out_is_f32 ? 4 : 2;
-            int rc = gemm_h16(fmt, A, lda, W, ldw, m1, N, K, bias, gamma, add_table, out, ldo, out_is_f32, accumulate, act, 0, 0, 0,
-                              stream);
-            if (rc) return rc;
-            return gemm_h16(fmt, (const char*)A + (long)m1 * lda * 2, lda, W, ldw, rem, N, K, bias, gamma, add_table,
-                            (char*)out + (long)m1 * ldo * esz, ldo, out_is_f32, accumulate, act, 0, 0, 0, stream);
-        }
-    }
+    const long slots = 512, t192 = (long)((M + 191) / 192) * (N / 128);
+    const long cost256 = (duo_tiles + slots - 1) / slots * 256, cost192 = (t192 + slots - 1) / slots * 192;
+    const int rows = (duo192 && cost192 < cost256) ? 192 : 256;
+    // (An earlier remedy for the qkv shape -- 21 x 24 full 256-row tiles here + the last 120 rows on the 128^2 kernel, 61.7 us --
+    // is gone: wherever it saved a round, 192-row tiles save it too and win.)
     if ((duo == 1 || duo_auto) && M >= 512 && (N % 128) == 0 && force_small_tile() == 0) {
-        const int rc = iggt_launch_gemm_duo(p, fmt, (hipStream_t)stream);
+        const int rc = iggt_launch_gemm_duo(p, fmt, rows, (hipStream_t)stream);
         if (rc == 0) {
             IGGT_CHECK_LAUNCH();
             return 0;

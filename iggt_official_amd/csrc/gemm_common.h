@@ -117,4 +117,4 @@ IGGT_DEVINL void gemm_epilogue_row4_nobias(const GemmParams& p, f32x4 v, int m, 
 // returns -100 when the parameter combination has no specialised big-tile kernel (caller falls back)
 int iggt_launch_gemm_t256(const GemmParams& p, int fmt, hipStream_t stream);
 // 256 x 128 tile, two workgroups per CU (gemm_bf16_duo.hip); same return convention
-int iggt_launch_gemm_duo(const GemmParams& p, int fmt, hipStream_t stream);
+int iggt_launch_gemm_duo(const GemmParams& p, int fmt, int rows, hipStream_t stream);

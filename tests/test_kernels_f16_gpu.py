@@ -42,12 +42,14 @@ def test_gemm_f16_mixed_operands_rejected(C):
 
 @pytest.mark.parametrize("M,N,K,mode", [(5000, 4096, 1024, "gelu"), (4122, 1024, 4096, "acc"), (2738, 1024, 640, "remap"),
                                         (43968, 3072, 1024, "plain"), (300, 256, 128, "gelu"),
-                                        (9000, 4096, 1024, "gelu"), (8448, 1024, 4096, "acc"), (5496, 3072, 1024, "gelu")])
+                                        (9000, 4096, 1024, "gelu"), (8448, 1024, 4096, "acc"), (5496, 3072, 1024, "gelu"),
+                                        (5496, 4096, 1024, "gelu"), (5496, 1024, 4096, "acc"), (5400, 1024, 4096, "plain")])
 def test_gemm_f16_epilogues(C, M, N, K, mode):
     """All three GEMM kernels: 1 024 <= M < 8 192 is the 256 x 128 two-workgroups-per-CU kernel (gemm_bf16_duo.hip: the
     per-rank shapes of a sharded run), M >= 8 192 the 256 x 256 LDS-DMA ping-pong kernel (gemm_bf16_t256.hip: ragged last
     row tile, GELU from the LDS table / LayerScale-accumulate epilogues), the small shape the 128 x 128 kernel; M = 5 496 x N =
-    3 072 (the per-rank qkv shape) is split into 21 full row tiles on the 256 x 128 kernel + the last 120 rows on the 128 x 128 one."""
+    3 072 | 4 096 | 1 024 (per-rank qkv / fc1 / fc2) and the fp32-output case at M = 5 400 take the 192-row variant of the
+    two-workgroups-per-CU kernel (fewer rounds x rows of the 512 workgroup slots; the last row tile is 120 | 24 rows)."""
     a = _rand((M, K), 70, dtype=F16)
     w = _rand((N, K), 71, K ** -0.5, dtype=F16)
     bias, gamma = _rand((N,), 72, 0.1), _rand((N,), 73)
