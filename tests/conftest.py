@@ -39,8 +39,26 @@ def report(key, value):
 
 
 def pytest_sessionfinish(session, exitstatus):
-    if _REPORT:
-        out = os.path.join(ROOT, "gpurun_out")
+    """One report per run.  Under pytest-xdist every worker writes its own part and the controller (whose session ends after
+    the workers') merges them."""
+    import glob
+
+    out = os.path.join(ROOT, "gpurun_out")
+    worker = os.environ.get("PYTEST_XDIST_WORKER")
+    if worker:
+        if _REPORT:
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, f"parity_report_part_{worker}.json"), "w") as f:
+                json.dump(_REPORT, f)
+        return
+    merged = dict(_REPORT)
+    for part in sorted(glob.glob(os.path.join(out, "parity_report_part_*.json"))):
+        try:
+            merged.update(json.load(open(part)))
+        except Exception:
+            pass
+        os.remove(part)
+    if merged:
         os.makedirs(out, exist_ok=True)
         path = os.path.join(out, "parity_report.json")
         old = {}
@@ -49,6 +67,6 @@ def pytest_sessionfinish(session, exitstatus):
                 old = json.load(open(path))
             except Exception:
                 old = {}
-        old.update(_REPORT)
+        old.update(merged)
         with open(path, "w") as f:
             json.dump(old, f, indent=1, sort_keys=True)
