@@ -198,7 +198,7 @@ static int flash_attn_static_h16(int fmt, const void* q, const void* k, const vo
     p.qkmax = qkmax; p.flags = flags; p.guard = guard; p.guard_prev = guard_prev;
     p.static_min_l = fmt == FMT_F16 ? STATIC_MIN_L_PER_KEY_F16 * (float)Nk : STATIC_MIN_L_BF16;
     const bool est = est_ws != nullptr;
-    // IGGT_EST_DEBUG (developer bit mask, bisecting): 1 no memset of the dense marks, 2 no key scan, 4 no pre-pass, 8 no
+    // IGGT_EST_DEBUG (developer bit mask, bisecting FAULTS -- results are not meaningful): 1 no memset of the dense marks, 2 no key scan, 4 no pre-pass, 8 no
     // estimated-shift instantiation, 16 no row list (the online-max pass then sees no workspace), 32 no second chance
     static int dbg = -1;
     if (dbg < 0) {

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
             const EstView ev = est_view(p);
             qr = ev.slotrow[(long)bh * ev.NqS + qr];
         }
-        qr = qr < p.Nq ? qr : p.Nq - 1;
+        qr = (unsigned)qr < (unsigned)p.Nq ? qr : p.Nq - 1;   // (unsigned: a slot table nobody wrote must not index backwards)
         if constexpr (!STATIC || LIST) {
             if (rlist != nullptr) qr = rlist[q_base + qb * 32 + frow < nlist ? q_base + qb * 32 + frow : nlist - 1];
         }
@@ -312,8 +312,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                 const EstView ev = est_view(p);
                 const int* sr = ev.slotrow + (long)bh * ev.NqS + q_base + frow;
                 const int r0 = sr[0], r1 = sr[32];
-                shift = rs[r0 < p.Nq ? r0 : p.Nq - 1] - EST_BIAS;
-                const float sh1 = rs[r1 < p.Nq ? r1 : p.Nq - 1] - EST_BIAS;
+                shift = rs[(unsigned)r0 < (unsigned)p.Nq ? r0 : p.Nq - 1] - EST_BIAS;
+                const float sh1 = rs[(unsigned)r1 < (unsigned)p.Nq ? r1 : p.Nq - 1] - EST_BIAS;
                 if constexpr (EST_NODELTA) shift = fmaxf(shift, sh1);
                 else est_delta = sh1 - shift;
             } else {
@@ -534,6 +534,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         if constexpr (EST && QB == 2) {
             const EstView ev = est_view(p);
             qr = ev.slotrow[(long)bh * ev.NqS + qr];    // re-read: nothing extra stays alive across the tile loop
+            qr = (unsigned)qr < (unsigned)p.Nq ? qr : p.Nq;   // slots past the end (and anything out of range): not stored
         }
         const float l = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
         const float inv = (PART && !(l > 0.f)) ? 0.f : 1.0f / l;
