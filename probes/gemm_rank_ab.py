@@ -55,7 +55,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--worker":
         worker(int(sys.argv[2]))
     else:
-        for views in (4, 8):
+        for views in ([int(v) for v in sys.argv[1:]] or [4, 8]):
             for env in ({}, {"IGGT_GEMM_DUO192": "0"}, {"IGGT_GEMM_DUO": "1"}, {"IGGT_GEMM_DUO": "1", "IGGT_GEMM_DUO192": "0"}):
                 print(f"# {views} views, {env or 'default'}", flush=True)
                 subprocess.check_call([sys.executable, os.path.abspath(__file__), "--worker", str(views)], env=dict(os.environ, **env))
