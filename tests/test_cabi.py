@@ -108,3 +108,19 @@ def test_attention_dispatcher_tile_choices(lib):
     per_rank = lab(1, 5496, 43968, True)
     assert "key ranges" in per_rank and "attn_combine_kernel" in per_rank
     assert "online-max" in lab(1, 5496, 43968, False)
+
+
+def test_estimated_shift_workspace_layout_matches_the_python_views(lib):
+    """The typed views the tests, probes and reports take into an est_ws buffer (_C.static_attn_est_views) must end exactly
+    where iggt_flash_attn_static_est_ws_bytes says the buffer ends (csrc/attention_common.h est_offsets), for ragged and
+    aligned shapes; the slot table of the 256-row kernel covers whole tiles."""
+    import torch
+
+    from iggt_official_amd import _C
+
+    for B, H, Nq, Nk in [(1, 16, 43968, 43968), (1, 16, 5496, 43968), (2, 4, 300, 700), (3, 16, 1374, 1374), (1, 1, 1, 1)]:
+        n = _C.static_attn_est_ws_bytes(B, H, Nq, Nk)
+        v = _C.static_attn_est_views(torch.zeros(n, dtype=torch.uint8), B, H, Nq, Nk)
+        assert v["bytes"] == n, (B, H, Nq, Nk, v["bytes"], n)
+        assert v["slotrow"].shape == (B * H, (Nq + 255) // 256 * 256)
+        assert v["rowshift"].shape == (B * H, Nq) and v["rowflag"].shape[1] % 16 == 0
