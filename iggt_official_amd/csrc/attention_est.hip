@@ -310,11 +310,10 @@ __global__ __launch_bounds__(256) void attn_rowshift_kernel(const AttnParams p, 
     }
     if (MODE == 1) return;
     // The 256-row static kernel gives each lane TWO rows (query blocks 0 and 1) and applies the second row's own shift by 16
-    // packed adds per key tile -- 0.3 ms per launch at N = 43 968.  Waves whose 32 row pairs all agree to within half a bit skip
+    // packed adds per key tile -- 0.3 ms per launch at N = 43 968.  Waves whose 32 row pairs all agree to within 8 bits skip
     // those adds (a second copy of the tile loop, chosen per wave), so the rows of the tile are dealt to the lanes in the order
-    // of their shift: slot (wave w, block qb, lane row f) gets sorted entry 2 (32 w + f) + qb.  Where shifts vary smoothly over
-    // the rows (trained-like affines: 0.1 bit between neighbours of the order) nearly every wave qualifies; where a few sink
-    // keys spread them over hundreds of bits, none does and nothing is lost.
+    // of their shift: slot (wave w, block qb, lane row f) gets sorted entry 2 (32 w + f) + qb, the second block the larger
+    // shift of the pair (attention_v3.hip IGGT_EST_DELTA_MAX for why that direction is the safe one).
     __syncthreads();
     for (int k = 2; k <= 256; k <<= 1) {        // bitonic sort of the tile's 256 (shift, row) pairs, ascending; ties by row
         for (int jj = k >> 1; jj > 0; jj >>= 1) {

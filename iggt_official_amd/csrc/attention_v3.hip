@@ -65,6 +65,14 @@ constexpr bool EST_NODELTA = true;
 #else
 constexpr bool EST_NODELTA = false;
 #endif
+// Largest difference (bits) between the shifts of a lane's two rows that a wave leaves uncorrected.  The rows are dealt in
+// ascending shift order, so the second row's own shift is the LARGER one: computed under the first row's it keeps
+// 2^(3 + delta) for its sampled maximum (the acceptance test only gets easier) and loses delta of its 13 bits of overflow
+// headroom -- an overflow is detected and the row handed over, never wrong.  Measured (profiles/r04_attn_est_ab.txt, est forced,
+// N = 43 968): 0.5 -> 8 bits takes 0.2-0.3 ms off the three adversarial regimes for 1-6 % more rows handed over; 12 is no better.
+#ifndef IGGT_EST_DELTA_MAX
+#define IGGT_EST_DELTA_MAX 8.0f
+#endif
 
 #ifdef IGGT_ATTN_NO_PIN   // A/B builds only (probes/build_alt.py)
 constexpr bool PIN_DEFAULT = false;
@@ -519,9 +527,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         }
     };
     if constexpr (EST && QB == 2 && !EST_NODELTA) {
-        // per wave: only if some lane's two rows differ by more than half a bit (the pre-pass dealt the rows in shift order, so
-        // neighbours rarely do); half a bit keeps the uncorrected row's largest numerator above the acceptance threshold
-        if (__any(fabsf(est_delta) > 0.5f)) tile_loop(std::true_type{});
+        // per wave: only if some lane's two rows differ by more than IGGT_EST_DELTA_MAX bits (the pre-pass dealt the rows in
+        // shift order, so neighbours rarely do)
+        if (__any(fabsf(est_delta) > IGGT_EST_DELTA_MAX)) tile_loop(std::true_type{});
         else tile_loop(std::false_type{});
     } else {
         tile_loop(std::false_type{});

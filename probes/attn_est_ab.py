@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the estimated-shift instantiation of the static attention kernel (probes/build_alt.py est_* variants vs the in-tree
-library): est forced, fp16, N = 43 968, LayerNorm-of-noise and sink-key operands; median of 7 launches and the largest
+library): est forced, fp16, N = 43 968, the four score regimes of probes/attn_static_robustness.py; median of 7 launches and the largest
 difference to the online-max kernel's output.  Usage: python probes/attn_est_ab.py > profiles/r04_attn_est_ab.txt"""
 import os
 import subprocess
@@ -18,7 +18,7 @@ def worker():
     from iggt_official_amd import _C
 
     H, C, P, T = r.H, r.C, r.P, r.T
-    for kind in ("noise", "sinks"):
+    for kind in ("noise", "affine", "sinks", "registers"):
         qkv, qkmax = r.make(kind, torch.float16)
         o = torch.empty(T, C, dtype=torch.float16, device="cuda")
         o_ref = torch.empty_like(o)

@@ -18,6 +18,8 @@ VARIANTS = {
     "est_default_sched": {"attention_v3_est.hip": []},
     "est_nodelta_maxilp": {"attention_v3_est.hip": ["-DIGGT_EST_NODELTA", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]},
     "est_nodelta": {"attention_v3_est.hip": ["-DIGGT_EST_NODELTA"]},
+    **{f"est_dmax{d}": {"attention_v3_est.hip": [f"-DIGGT_EST_DELTA_MAX={d}.0f", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+       for d in (1, 2, 3, 4, 6, 8, 12)},
     # LLVM scheduling strategies on the three matrix-pipe kernels (timed by probes/sched_ab.py); iterative-ilp does not get
     # through attention_v3.hip (compiler error)
     **{f"sched_{n}": {f: fl for f in ("attention_v3.hip", "gemm_bf16_t256.hip", "conv3x3_halo.hip")}
