@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -65,6 +65,11 @@ _SIGNATURES = {
                              _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_long, _c_long, _c_float, _c_void_p,
                              _c_void_p],
     "iggt_im2row_patch14": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p],
+    "iggt_qkv_split_f16": [_c_void_p, _c_long, _c_void_p, _c_long, _c_long, _c_void_p, _c_long, _c_long, _c_void_p, _c_long,
+                           _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                           _c_int, _c_float, _c_float, _c_void_p],
+    "iggt_split3_f16": [_c_void_p, _c_long, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_void_p],
+    "iggt_flash_attn_x3_f16_d64": [_c_void_p] * 7 + [_c_long] + [_c_int] * 4 + [_c_long] * 8 + [_c_void_p],
     "iggt_colmean_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "iggt_bias_correct_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
     "iggt_head_tail_f32": [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int,
@@ -378,18 +383,22 @@ def attn_kernel_label(B, H, Nq, Nk, operand_name, static_bound=False, q_rows_per
 
 
 def layernorm(x0, w, b, out, eps, *, x1=None, rows=None, rows_in=0, rows_stride=0, row_off=0,
-              orows_stride=0, orow_off=0, ldx=None, ldo=None):
-    """LayerNorm over the last dim of x0 (or of concat(x0, x1)); fp32 in, bf16 / fp16 / fp32 out [rows, C]."""
+              orows_stride=0, orow_off=0, ldx=None, ldo=None, split3=False):
+    """LayerNorm over the last dim of x0 (or of concat(x0, x1)); fp32 in, bf16 / fp16 / fp32 out [rows, C].
+    split3: out is fp16 [rows, 3 C] = [hi | lo | hi] (the x3 precision rung, include/iggt_hip.h)."""
     _dev(x0, x1, w, b, out)
     assert x0.dtype == torch.float32 and x0.stride(-1) == 1 and out.stride(-1) == 1
     C = x0.shape[-1] * (2 if x1 is not None else 1)
+    if split3:
+        assert out.dtype == torch.float16 and out.shape[-1] == 3 * C
     rows = out.shape[0] if rows is None else rows
     ld0 = x0.stride(-2) if ldx is None else ldx
     ld1 = 0 if x1 is None else (x1.stride(-2) if ldx is None else ldx)
     rc = load().iggt_layernorm_f32(x0.data_ptr(), ld0, _ptr(x1), ld1,
                                    w.data_ptr(), b.data_ptr(), out.data_ptr(),
                                    out.stride(-2) if ldo is None else ldo,
-                                   {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}[out.dtype], rows, C, float(eps),
+                                   3 if split3 else {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}[out.dtype], rows, C,
+                                   float(eps),
                                    rows_in, rows_stride, row_off, orows_stride, orow_off, _stream())
     _check(rc, "iggt_layernorm_f32")
     return out
@@ -410,13 +419,55 @@ def qknorm_rope(qkv, q_out, k_out, v_out, qw, qb, kw, kb, cos_t, sin_t, T, P, gw
     _check(rc, "iggt_qknorm_rope_" + sfx)
 
 
-def im2row_patch14(img, out, S, H, W, Kpad):
+def im2row_patch14(img, out, S, H, W, Kpad, split3=False):
+    """split3: out fp16 [rows, 3 Kpad] = [hi | lo | hi] (x3 precision rung)."""
     _dev(img, out)
-    assert img.dtype == torch.float32 and img.is_contiguous() and out.dtype in H16
-    rc = load().iggt_im2row_patch14(img.data_ptr(), out.data_ptr(), int(out.dtype == torch.float16), S, H, W, Kpad,
-                                    _stream())
+    assert img.dtype == torch.float32 and img.is_contiguous() and out.dtype in H16 and out.is_contiguous()
+    assert not split3 or (out.dtype == torch.float16 and out.shape[-1] == 3 * Kpad)
+    rc = load().iggt_im2row_patch14(img.data_ptr(), out.data_ptr(), 2 if split3 else int(out.dtype == torch.float16), S, H, W,
+                                    Kpad, _stream())
     _check(rc, "iggt_im2row_patch14")
     return out
+
+
+# ---- x3 precision rung (include/iggt_hip.h, csrc/x3.hip): fp16 hi + lo operand pairs, three MFMA passes per product ------------
+def qkv_split(qkv32, q_out, q_lo, k_out, k_lo, v_out, v_lo, *, qw=None, qb=None, kw=None, kb=None, cos_t=None, sin_t=None,
+              P=1, gw=1, patch_start=0, eps=1e-5, q_scale=1.0):
+    """qkv32 fp32 [T, 3072] -> optional q/k LayerNorm(64) + RoPE -> q * q_scale, k, v as fp16 pairs: hi into q_out / k_out / v_out
+    ([T, 1024] views, row stride ok), lo the given number of ELEMENTS behind each."""
+    _dev(qkv32, q_out, k_out, v_out, qw, cos_t)
+    assert qkv32.dtype == torch.float32 and qkv32.shape[-1] == 3072 and qkv32.stride(-1) == 1
+    for t in (q_out, k_out, v_out):
+        assert t.dtype == torch.float16 and t.stride(-1) == 1
+    for t in (qw, qb, kw, kb, cos_t, sin_t):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    rc = load().iggt_qkv_split_f16(qkv32.data_ptr(), qkv32.stride(0), q_out.data_ptr(), q_out.stride(0), int(q_lo),
+                                   k_out.data_ptr(), k_out.stride(0), int(k_lo), v_out.data_ptr(), v_out.stride(0), int(v_lo),
+                                   _ptr(qw), _ptr(qb), _ptr(kw), _ptr(kb), _ptr(cos_t), _ptr(sin_t), qkv32.shape[0], int(P),
+                                   int(gw), int(patch_start), float(eps), float(q_scale), _stream())
+    _check(rc, "iggt_qkv_split_f16")
+
+
+def split3(x, out, act=0):
+    """x fp32 [rows, N] -> (act = 1: exact GELU) -> out fp16 [rows, 3 N] = [hi | lo | hi]."""
+    _dev(x, out)
+    assert x.dtype == torch.float32 and out.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1
+    assert out.shape == (x.shape[0], 3 * x.shape[1])
+    _check(load().iggt_split3_f16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1], int(act),
+                                  _stream()), "iggt_split3_f16")
+    return out
+
+
+def flash_attn_x3(q, q_lo, k, k_lo, v, v_lo, o, o_seg, B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs):
+    """Attention on fp16 hi / lo pairs (q carries scale * log2 e); o gets [hi | lo | hi] segments o_seg elements apart (0: hi only)."""
+    _dev(q, q_lo, k, k_lo, v, v_lo, o)
+    for t in (q, q_lo, k, k_lo, v, v_lo, o):
+        assert t.dtype == torch.float16
+    rc = load().iggt_flash_attn_x3_f16_d64(q.data_ptr(), q_lo.data_ptr(), k.data_ptr(), k_lo.data_ptr(), v.data_ptr(),
+                                           v_lo.data_ptr(), o.data_ptr(), int(o_seg), B, H, Nq, Nk, q_bs, q_rs, k_bs, k_rs,
+                                           v_bs, v_rs, o_bs, o_rs, _stream())
+    _check(rc, "iggt_flash_attn_x3_f16_d64")
+    return o
 
 
 def colmean(x, mu, row_step=1):

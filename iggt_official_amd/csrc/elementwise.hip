@@ -26,6 +26,8 @@ struct LnParams {
     long ldo;
     float* out_f32;  // optional fp32 output instead of the 16-bit one
     int f16;         // 16-bit output format: 0 bf16, 1 fp16
+    long split_seg;  // > 0 (fp16 only; round 5, the x3 precision rung of layers/blocks.py): the row is written as fp16 hi at +0, lo =
+                     // fp16(y - hi) at +split_seg and hi again at +2 split_seg -- the A' = [A_hi | A_lo | A_hi] operand of a three-pass GEMM
     int rows;
     float eps;
     int rows_in, rows_stride, row_off;  // in_row = (r / rows_in) * rows_stride + row_off + r % rows_in
@@ -81,6 +83,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
             o[0] = p.f16 ? pack_h2<FMT_F16>(y[0], y[1]) : pack_h2<FMT_BF16>(y[0], y[1]);
             o[1] = p.f16 ? pack_h2<FMT_F16>(y[2], y[3]) : pack_h2<FMT_BF16>(y[2], y[3]);
             *reinterpret_cast<u32x2*>(p.out + orow * p.ldo + col) = o;
+            if (p.split_seg > 0) {
+                u32x2 lo;
+                lo[0] = pack_h2<FMT_F16>(y[0] - h2_lo<FMT_F16>(o[0]), y[1] - h2_hi<FMT_F16>(o[0]));
+                lo[1] = pack_h2<FMT_F16>(y[2] - h2_lo<FMT_F16>(o[1]), y[3] - h2_hi<FMT_F16>(o[1]));
+                *reinterpret_cast<u32x2*>(p.out + orow * p.ldo + p.split_seg + col) = lo;
+                *reinterpret_cast<u32x2*>(p.out + orow * p.ldo + 2 * p.split_seg + col) = o;
+            }
         }
     }
 }
@@ -306,6 +315,7 @@ struct Im2rowParams {
     const float* img;  // [S][3][H][W] in [0,1]
     bf16_t* out;       // [S*gh*gw][Kpad]
     int S, H, W, gh, gw, Kpad;
+    int split;
 };
 
 template <int FMT>
@@ -331,7 +341,15 @@ __global__ __launch_bounds__(256) void im2row_patch14_kernel(const Im2rowParams 
                 v[e] = 0.f;
             }
         }
-        *reinterpret_cast<uint32_t*>(p.out + row * p.Kpad + kp * 2) = pack_h2<FMT>(v[0], v[1]);
+        if (p.split) {   // fp16 [hi | lo | hi], row stride 3 Kpad (the x3 precision rung)
+            const uint32_t hi = pack_h2<FMT>(v[0], v[1]);
+            bf16_t* d = p.out + row * (3L * p.Kpad) + kp * 2;
+            *reinterpret_cast<uint32_t*>(d) = hi;
+            *reinterpret_cast<uint32_t*>(d + p.Kpad) = pack_h2<FMT>(v[0] - h2_lo<FMT>(hi), v[1] - h2_hi<FMT>(hi));
+            *reinterpret_cast<uint32_t*>(d + 2 * p.Kpad) = hi;
+        } else {
+            *reinterpret_cast<uint32_t*>(p.out + row * p.Kpad + kp * 2) = pack_h2<FMT>(v[0], v[1]);
+        }
     }
 }
 
@@ -601,11 +619,13 @@ extern "C" int iggt_layernorm_f32(const float* x0, long ld0, const float* x1, lo
                                   const float* b, void* out, long ldo, int out_type, int rows, int C,
                                   float eps, int rows_in, int rows_stride, int row_off, int orows_stride, int orow_off,
                                   void* stream) {
-    if (rows <= 0 || out_type < 0 || out_type > 2) return -1;
+    if (rows <= 0 || out_type < 0 || out_type > 3) return -1;
     if ((ld0 % 4) || (x1 && (ld1 % 4)) || (ldo % 4)) return -2;
+    if (out_type == 3 && (ldo < 3L * C || C < 256)) return -2;   // [hi | lo | hi], segments C apart
     const int out_is_f32 = out_type == 1;
     LnParams p;
-    p.f16 = out_type == 2;
+    p.f16 = out_type >= 2;
+    p.split_seg = out_type == 3 ? C : 0;
     p.x0 = x0; p.x1 = x1; p.ld0 = ld0; p.ld1 = ld1; p.w = w; p.b = b;
     p.out = out_is_f32 ? nullptr : (bf16_t*)out;
     p.out_f32 = out_is_f32 ? (float*)out : nullptr;
@@ -694,9 +714,10 @@ extern "C" int iggt_k_rownorm_max_f16(const void* k, long ldk, int rows, float* 
 
 extern "C" int iggt_im2row_patch14(const float* img, void* out, int out_f16, int S, int H, int W, int Kpad,
                                    void* stream) {
-    if (S <= 0 || (H % 14) || (W % 14) || Kpad < 588 || (Kpad % 64)) return -1;
+    if (S <= 0 || (H % 14) || (W % 14) || Kpad < 588 || (Kpad % 64) || out_f16 < 0 || out_f16 > 2) return -1;
     Im2rowParams p;
     p.img = img; p.out = (bf16_t*)out; p.S = S; p.H = H; p.W = W; p.gh = H / 14; p.gw = W / 14; p.Kpad = Kpad;
+    p.split = out_f16 == 2;   // fp16 [hi | lo | hi] rows of 3 Kpad (round 5)
     const long total = (long)S * p.gh * p.gw * (Kpad / 2);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 16) blocks = 256 * 16;

@@ -108,6 +108,15 @@ def _h16_residual(w: torch.Tensor, dt: torch.dtype):
     return (w - w.to(dt).float()).to(dt).contiguous()
 
 
+def _x3_weight(w: torch.Tensor):
+    """W' = [W_hi | W_hi | W_lo] (fp16, [N, 3 K]) for the three-pass GEMM of the x3 precision rung against A' = [A_hi | A_lo | A_hi]
+    (csrc/x3.hip): A W^T ~= A_hi W_hi^T + A_lo W_hi^T + A_hi W_lo^T."""
+    w = w.detach().float()
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+    return torch.cat([hi, hi, lo], 1).contiguous()
+
+
 # Range folding (round 4).  fp16 operands hold |w| <= 65504; a checkpoint whose weights exceed that used to be sent to bf16
 # operands as a whole -- the mode that sits 6e-3 from the fp32 reference.  A block's four GEMMs sit between per-channel affines
 # that commute with a power-of-two rescaling EXACTLY (no rounding: only exponents change):
@@ -211,15 +220,40 @@ class Block(nn.Module):
         # While it is off the block issues exactly the round-3 launch sequence: the nine extra launches of the estimated-shift
         # sequence cost ~45 us per attention call even when every one of them returns at once (2 ms per 32-view forward).
         self._est_on = False
+        # precision rung (precision.py "x3"): the owner of a block SEQUENCE (models/aggregator.py plan_escalation) asks for the x3
+        # path here when this block or ANY LATER block of the sequence is ill-conditioned by its own figures -- an ill-conditioned
+        # block amplifies the operand rounding of everything upstream of it, so escalating it alone does not help (CPU
+        # simulation, profiles/r05_escalation_policy.txt: sigma_qk = 1 with only the sharp-softmax blocks escalated 5.2e-3, with
+        # all of them 1.8e-5).  None: a block used on its own decides from its own figures.
+        self._x3_request: Optional[bool] = None
+        self._cond = None
+        self._cond_key = None
 
     # ------------------------------------------------------------------------------------------
+    def own_condition(self) -> dict:
+        """precision.block_condition of this block's parameters as stored (cached per parameter version; the first call after a
+        change reads a few scalars back from the device)."""
+        ps = [self.norm1.weight, self.norm2.weight]
+        if self.attn.qk_norm:
+            ps += [self.attn.q_norm.weight, self.attn.k_norm.weight]
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        if self._cond_key != key:
+            self._cond = precision.block_condition(ps[0], ps[1], ps[2] if self.attn.qk_norm else None,
+                                                   ps[3] if self.attn.qk_norm else None, self.attn.scale)
+            self._cond_key = key
+        return self._cond
+
+    def own_escalation(self) -> bool:
+        return precision.should_escalate(self.own_condition())
+
     def packed(self):
         """16-bit (precision.operand_dtype()) copies of the four GEMM weights + fp32 epilogue vectors, rebuilt when
         params or the operand format change."""
         ps = (self.attn.qkv.weight, self.attn.proj.weight, self.mlp.fc1.weight, self.mlp.fc2.weight)
         dt = precision.operand_dtype()
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (dt, precision.mean_compensation_sites(),
-                                                                              precision.range_folding())
+                                                                              precision.range_folding(), precision.escalation(),
+                                                                              self._x3_request)
         if self._packed_key != key:
             if self._packed is not None:
                 graphs.buffers_changed()    # the old packs are freed below; captured graphs hold their addresses
@@ -257,6 +291,22 @@ class Block(nn.Module):
                     n2w, n2b = f32(self.norm2.weight), f32(self.norm2.bias)
                     folded = 0
             cont = lambda t: None if t is None else t.contiguous()  # noqa: E731
+            # per-block precision rung (precision.py "x3"): decided from this block's own LayerNorm / q-k-norm scales as stored
+            cond = self.own_condition()
+            x3 = self.own_escalation() if self._x3_request is None else (self._x3_request and precision.escalation() != "off")
+            if dt == torch.float16 and x3:
+                self._packed = dict(
+                    x3=True, condition=cond, folded_slices=folded,
+                    w3_qkv=_x3_weight(wq), b_qkv=cont(bq), w3_proj=_x3_weight(wp), b_proj=cont(bp),
+                    w3_fc1=_x3_weight(w1), b_fc1=cont(b1), w3_fc2=_x3_weight(w2), b_fc2=cont(b2),
+                    g1=g1.contiguous(), g2=g2.contiguous(),
+                    n1w=n1w.contiguous(), n1b=n1b.contiguous(), n2w=n2w.contiguous(), n2b=n2b.contiguous())
+                if self.attn.qk_norm:
+                    self._packed.update(qw=f32(self.attn.q_norm.weight), qb=f32(self.attn.q_norm.bias),
+                                        kw=f32(self.attn.k_norm.weight), kb=f32(self.attn.k_norm.bias))
+                self._est_on = False
+                self._packed_key = key
+                return self._packed
             self._packed = dict(
                 w_qkv=_h16_weight(wq, dt, ROW_PAD), b_qkv=cont(bq),
                 w_proj=_h16_weight(wp, dt), b_proj=cont(bp),
@@ -264,7 +314,7 @@ class Block(nn.Module):
                 w_fc2=_h16_weight(w2, dt), b_fc2=cont(b2),
                 g1=g1.contiguous(), g2=g2.contiguous(),
                 n1w=n1w.contiguous(), n1b=n1b.contiguous(), n2w=n2w.contiguous(), n2b=n2b.contiguous(),
-                folded_slices=folded,
+                folded_slices=folded, x3=False, condition=cond, bf16_fallback=(dt != precision.operand_dtype()),
             )
             comp = precision.mean_compensation_sites() if dt == torch.float16 else frozenset()
             for n, w_ in (("qkv", wq), ("proj", wp), ("fc1", w1), ("fc2", w2)):
@@ -302,6 +352,8 @@ class Block(nn.Module):
         dev = x2d.device
         pk = self.packed()
         H = self.attn.num_heads
+        if pk["x3"]:
+            return self._forward_x3(x2d, ws, pk, batch=batch, tokens=tokens, rope_geom=rope_geom, kv_gather=kv_gather)
         dt = pk["w_qkv"].dtype  # 16-bit operand format of this block (bf16 for a block whose weights could not be folded)
         alt = "" if dt == precision.operand_dtype() else "_alt"   # its own buffers: no reallocation when neighbours differ
         xn = ws.get_padded("xn" + alt, T, C, dt, dev)
@@ -415,6 +467,66 @@ class Block(nn.Module):
         b_ = compensated_bias(ws, hid, pk["dw_fc2"], pk["b_fc2"])
         with profiling.region("gemm", ("fc2", T, C, hid.shape[1])):
             _C.gemm_h16(hid, pk["w_fc2"], x2d, bias=b_, gamma=pk["g2"], accumulate=True)
+        return x2d
+
+    def _forward_x3(self, x2d, ws, pk, *, batch, tokens, rope_geom, kv_gather):
+        """The block on fp16 hi + lo operand PAIRS, three MFMA passes per product (precision.py "x3", csrc/x3.hip): same data
+        flow as forward_inplace, every 16-bit rounding site replaced by a 22-bit one.
+          LayerNorm -> [hi | lo | hi]  --GEMM K = 3C, fp32 out-->  qkv fp32  -> q/k-norm + RoPE + split -> attention on pairs ->
+          [hi | lo | hi]  --GEMM, LayerScale + residual-->  x;   LayerNorm -> [hi | lo | hi] -> fc1 fp32 -> exact GELU + split ->
+          fc2, LayerScale + residual.
+        No mean-input compensation (the weights are pairs too), no static softmax (online maximum in fp32).  Multi-GPU: K and V
+        pairs travel as one [T_local, 4C] message, the gather completes before the one attention launch."""
+        T, C = x2d.shape
+        dev = x2d.device
+        H = self.attn.num_heads
+        Hd = pk["w3_fc1"].shape[0]
+        f16 = torch.float16
+        xn3 = ws.get("x3_xn", (T, 3 * C), f16, dev)
+        qkv32 = ws.get("x3_qkv32", (T, 3 * C), torch.float32, dev)
+        _C.layernorm(x2d, pk["n1w"], pk["n1b"], xn3, self.norm1.eps, split3=True)
+        with profiling.region("gemm", ("qkv_x3", T, 3 * C, 3 * C)):
+            _C.gemm_h16(xn3, pk["w3_qkv"], qkv32, bias=pk["b_qkv"])
+        q_scale = self.attn.scale * _C.LOG2E
+        norm = dict(qw=pk["qw"], qb=pk["qb"], kw=pk["kw"], kb=pk["kb"], eps=self.attn.q_norm.eps) if self.attn.qk_norm else {}
+        rope = {}
+        if self.attn.qk_norm:
+            assert rope_geom is not None
+            rope = dict(cos_t=rope_geom["cos"], sin_t=rope_geom["sin"], P=rope_geom["P"], gw=rope_geom["gw"],
+                        patch_start=rope_geom["patch_start"])
+        if kv_gather is None:
+            qkv6 = ws.get("x3_qkv6", (T, 6 * C), f16, dev)     # [q_hi | k_hi | v_hi | q_lo | k_lo | v_lo]
+            _C.qkv_split(qkv32, qkv6[:, :C], 3 * C, qkv6[:, C:2 * C], 3 * C, qkv6[:, 2 * C:3 * C], 3 * C, q_scale=q_scale,
+                         **norm, **rope)
+            q, q_lo, q_rs, q_bs = qkv6, qkv6[:, 3 * C:], 6 * C, tokens * 6 * C
+            k, k_lo, v, v_lo = qkv6[:, C:], qkv6[:, 4 * C:], qkv6[:, 2 * C:], qkv6[:, 5 * C:]
+            kv_rs, Nk, k_bs = 6 * C, tokens, tokens * 6 * C
+        else:
+            if not self.attn.qk_norm or batch != 1:
+                raise _C.HipExtensionError("kv_gather needs a q/k-norm block")
+            q2 = ws.get("x3_q2", (T, 2 * C), f16, dev)                 # [q_hi | q_lo]
+            kv_local = ws.get("x3_kv_local", (T, 4 * C), f16, dev)     # [k_hi | v_hi | k_lo | v_lo]: one gather message
+            _C.qkv_split(qkv32, q2[:, :C], C, kv_local[:, :C], 2 * C, kv_local[:, C:2 * C], 2 * C, q_scale=q_scale, **norm,
+                         **rope)
+            gather = kv_gather.all_gather_kv if hasattr(kv_gather, "all_gather_kv") else kv_gather
+            kv_all = gather(kv_local)
+            q, q_lo, q_rs, q_bs = q2, q2[:, C:], 2 * C, 0
+            k, k_lo, v, v_lo = kv_all, kv_all[:, 2 * C:], kv_all[:, C:], kv_all[:, 3 * C:]
+            kv_rs, Nk, k_bs = 4 * C, kv_all.shape[0], 0
+        ao3 = ws.get("x3_ao", (T, 3 * C), f16, dev)
+        with profiling.region("global_attn_x3" if batch == 1 else "frame_attn_x3", (batch, tokens, Nk)):
+            _C.flash_attn_x3(q, q_lo, k, k_lo, v, v_lo, ao3, C, batch, H, tokens, Nk, q_bs, q_rs, k_bs, kv_rs, k_bs, kv_rs,
+                             tokens * 3 * C, 3 * C)
+        with profiling.region("gemm", ("proj_x3", T, C, 3 * C)):
+            _C.gemm_h16(ao3, pk["w3_proj"], x2d, bias=pk["b_proj"], gamma=pk["g1"], accumulate=True)
+        _C.layernorm(x2d, pk["n2w"], pk["n2b"], xn3, self.norm2.eps, split3=True)
+        h32 = ws.get("x3_h32", (T, Hd), torch.float32, dev)
+        with profiling.region("gemm", ("fc1_x3", T, Hd, 3 * C)):
+            _C.gemm_h16(xn3, pk["w3_fc1"], h32, bias=pk["b_fc1"])
+        hid3 = ws.get("x3_hid", (T, 3 * Hd), f16, dev)
+        _C.split3(h32, hid3, act=1)
+        with profiling.region("gemm", ("fc2_x3", T, C, 3 * Hd)):
+            _C.gemm_h16(hid3, pk["w3_fc2"], x2d, bias=pk["b_fc2"], gamma=pk["g2"], accumulate=True)
         return x2d
 
     def _attend_overlapped(self, qkv, kv_local, shard, qkmax, ao, ws, T, H, C, guard=None, guard_prev=None, overlap=True):

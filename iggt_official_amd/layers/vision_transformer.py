@@ -118,6 +118,21 @@ class DinoVisionTransformer(nn.Module):
             self._cache["pw"] = (wp, self.patch_embed.proj.bias.detach().float().contiguous(), dwp)
         return self._cache["pw"]
 
+    def _packed_patch_weight_x3(self):
+        w = self.patch_embed.proj.weight
+        key = (w.data_ptr(), w._version)
+        if self._cache.get("pw3_key") != key:
+            if "pw3" in self._cache:
+                graphs.buffers_changed()
+            w2 = w.detach().reshape(w.shape[0], -1).float()
+            wpad = torch.zeros(w.shape[0], KPAD, dtype=torch.float32, device=w.device)
+            wpad[:, : w2.shape[1]] = w2
+            from .blocks import _x3_weight
+
+            self._cache["pw3_key"] = key
+            self._cache["pw3"] = _x3_weight(wpad)
+        return self._cache["pw3"]
+
     # ---- fused forward ---------------------------------------------------------------------------
     def forward_tokens(self, images: torch.Tensor) -> torch.Tensor:
         """images: raw [0,1] fp32 [S,3,H,W] on the GPU -> pre-norm tokens x fp32 [S, 5+g2, C]."""
@@ -137,11 +152,19 @@ class DinoVisionTransformer(nn.Module):
         images = images.contiguous().float()
         special, patch_pe = self._pos_tables(H, W)
         wp, bias, dwp = self._packed_patch_weight()
-        a = self._ws.get("im2row", (S * g2, KPAD), wp.dtype, dev)
-        _C.im2row_patch14(images, a, S, H, W, KPAD)
         x = torch.empty(S, P, D, dtype=torch.float32, device=dev)
-        _C.gemm_h16(a, wp, x.view(S * P, D), bias=compensated_bias(self._ws, a, dwp, bias), add_table=patch_pe,
-                     rows_in=g2, rows_out=P, row_off=nsp)
+        if any(blk.packed()["x3"] for blk in self.blocks):
+            # the patch embedding follows its consumers onto the x3 precision rung (precision.py): pixels and weights as fp16
+            # hi + lo pairs, one GEMM over the concatenated K axis (layers/blocks.py _x3_weight)
+            a3 = self._ws.get("im2row_x3", (S * g2, 3 * KPAD), torch.float16, dev)
+            _C.im2row_patch14(images, a3, S, H, W, KPAD, split3=True)
+            _C.gemm_h16(a3, self._packed_patch_weight_x3(), x.view(S * P, D), bias=bias, add_table=patch_pe, rows_in=g2,
+                         rows_out=P, row_off=nsp)
+        else:
+            a = self._ws.get("im2row", (S * g2, KPAD), wp.dtype, dev)
+            _C.im2row_patch14(images, a, S, H, W, KPAD)
+            _C.gemm_h16(a, wp, x.view(S * P, D), bias=compensated_bias(self._ws, a, dwp, bias), add_table=patch_pe,
+                         rows_in=g2, rows_out=P, row_off=nsp)
         _C.write_special_tokens(x, special, special, S, nsp, 0, False)
         x2d = x.view(S * P, D)
         for blk in self.blocks:

@@ -112,6 +112,7 @@ class Aggregator(nn.Module):
         C = self.camera_token.shape[-1]
         T = S * P
 
+        self.plan_escalation()
         # tokens[s] = [camera(1), register(4), normed DINOv2 patch tokens]   (aggregator.py:209-234)
         tokens = torch.empty(S, P, C, dtype=torch.float32, device=dev)
         self.patch_embed.patch_tokens_into(images[0], tokens, psi)
@@ -195,6 +196,36 @@ class Aggregator(nn.Module):
             from .. import graphs
 
             graphs.buffers_changed()    # captured graphs do not hold the estimated-shift launches of these blocks: re-capture
+
+    def execution_order(self):
+        """The 24 + 48 transformer blocks in the order the forward runs them."""
+        order = list(self.patch_embed.blocks)
+        for i in range(self.depth):
+            for kind in self.aa_order:
+                order.append(self.frame_blocks[i] if kind == "frame" else self.global_blocks[i])
+        return order
+
+    def plan_escalation(self):
+        """Per-block precision rung (precision.py "x3"): every block that is ill-conditioned by its own LayerNorm / q-k-norm
+        scales, and every block in front of it, runs on fp16 hi + lo operand pairs.  Returns the plan (72 booleans)."""
+        from .. import precision
+
+        return precision.plan_escalation(self.execution_order())
+
+    def escalation_report(self) -> dict:
+        """Which blocks run on the x3 rung / fell to bf16 operands (after a forward or `plan_escalation()`), and the worst
+        conditioning figures seen (precision.block_condition)."""
+        order = self.execution_order()
+        names = ([f"patch_embed.blocks.{i}" for i in range(len(self.patch_embed.blocks))]
+                 + [f"{k}_blocks.{i}" for i in range(self.depth) for k in self.aa_order])
+        conds = [b.own_condition() for b in order]
+        packs = [b._packed for b in order]
+        return dict(blocks=len(order),
+                    x3=[n for n, b in zip(names, order) if b._x3_request],
+                    own_verdict=[n for n, b in zip(names, order) if b.own_escalation()],
+                    bf16_fallback=[n for n, p in zip(names, packs) if p is not None and p.get("bf16_fallback")],
+                    min_participation_ratio=min(min(c["pr_norm1"], c["pr_norm2"]) for c in conds),
+                    max_logit_rms=max(c["logit_rms"] for c in conds))
 
     def static_softmax_stats(self) -> dict:
         """Adaptive-switch words of the 48 aggregator blocks after a forward (synchronises): per kind, the number of query

@@ -191,6 +191,73 @@ def set_range_folding(on: bool) -> None:
     _range_fold = bool(on)
 
 
+# Per-block precision rung "x3" (round 5; csrc/x3.hip, layers/blocks.py Block._forward_x3): a block whose own weights make the map
+# ill-conditioned for 11-bit operands runs every MFMA product on fp16 hi + lo PAIRS in three passes (22 significant bits, 3x the
+# MFMA work of that block).  Decided per block at pack time from the block's own parameters -- never globally:
+#   * participation ratio of the LayerNorm scales, PR(g) = (sum g^2)^2 / (C sum g^4) in (0, 1]: the share of the 1 024 channels
+#     that carries the normalised signal (1 for flat scales; 0.37 / 0.11 / 0.018 for log-normal scales of sigma 0.5 / 0.75 / 1).
+#     Below ESC_PR_MIN the reference's fp32 is still 1e-5 from fp64 while single fp16 operands leave 3e-3 .. 2e-2
+#     (profiles/r04_trained_like_sweep.txt, r05_precision_groups.txt);
+#   * predicted r.m.s. of the attention logits from the q/k-norm scales, scale * |g_q * g_k|_2 (1.0 for flat scales; measured
+#     2 / 5.5 / 15 at sigma 0.5 / 0.75 / 1): above ESC_LOGIT_RMS_MAX the softmax is sharp enough that operand rounding of q and k
+#     moves the probabilities by per cent.
+#     (thresholds: the sigma 0.75 / 0.5 fixture -- largest block 5.45, PR >= 0.27 -- passes 1e-3 on single fp16 operands and must
+#     not pay; sigma 1 / 0.5 -- median block 5.0, largest 15 -- does not.)
+# An ill-conditioned block AMPLIFIES the rounding of everything upstream of it, so the owner of a block sequence escalates a
+# block when it OR ANY LATER block trips a criterion (plan_escalation below; layers/blocks.py Block._x3_request).
+# IGGT_ESCALATE = auto (default) | off | all;  fp16 operands only (bf16 mode keeps the reference's autocast arithmetic).
+ESC_PR_MIN = 0.25
+ESC_LOGIT_RMS_MAX = 6.0
+_escalate = os.environ.get("IGGT_ESCALATE", "auto").lower()
+if _escalate not in ("auto", "off", "all"):
+    raise ValueError("IGGT_ESCALATE must be auto, off or all")
+
+
+def escalation() -> str:
+    return _escalate if _operand == torch.float16 else "off"
+
+
+def set_escalation(mode: str) -> None:
+    global _escalate
+    if mode not in ("auto", "off", "all"):
+        raise ValueError("escalation mode must be 'auto', 'off' or 'all'")
+    _escalate = mode
+
+
+def participation_ratio(g: torch.Tensor) -> float:
+    g2 = g.detach().double().flatten() ** 2
+    return float(g2.sum() ** 2 / (g2 * g2).sum().clamp_min(1e-300) / g2.numel())
+
+
+def block_condition(n1w, n2w, qw=None, kw=None, scale: float = 0.125) -> dict:
+    """Conditioning figures of one transformer block from its own parameters (see above); qw / kw: q_norm / k_norm scales of a
+    q/k-norm block, None for the DINOv2 blocks (their logits are not bounded by a norm; only the LayerNorm criterion applies)."""
+    c = dict(pr_norm1=participation_ratio(n1w), pr_norm2=participation_ratio(n2w), logit_rms=0.0)
+    if qw is not None and kw is not None:
+        c["logit_rms"] = float(scale * (qw.detach().double() * kw.detach().double()).norm())
+    return c
+
+
+def should_escalate(cond: dict) -> bool:
+    mode = escalation()
+    if mode != "auto":
+        return mode == "all"
+    return min(cond["pr_norm1"], cond["pr_norm2"]) < ESC_PR_MIN or cond["logit_rms"] > ESC_LOGIT_RMS_MAX
+
+
+def plan_escalation(blocks) -> list:
+    """blocks: layers.blocks.Block modules in EXECUTION order.  Sets every block's `_x3_request` to "this block or a later one is
+    ill-conditioned by its own figures" and returns the list of booleans.  Cheap after the first call (the figures are cached
+    per parameter version)."""
+    own = [b.own_escalation() for b in blocks]
+    need, plan = False, [False] * len(blocks)
+    for i in range(len(blocks) - 1, -1, -1):
+        need = need or own[i]
+        plan[i] = need
+        blocks[i]._x3_request = need
+    return plan
+
+
 def check_operand_range(name: str, w: torch.Tensor, dt: torch.dtype) -> None:
     """Weights are converted with a plain cast (no clamp): a value beyond the fp16 range would become inf and poison every
     output.  Called once per pack (blocks.py); the comparison runs on the device, the verdict is read back once."""

@@ -154,7 +154,8 @@ int iggt_flash_attn_d64_kernel_name(int B, int H, int Nq, int Nk, int f16, int s
                                     int q_rows_per_wg, char* buf, int buf_len);
 
 /* LayerNorm over C in {128 (no concat / remap), 256, 512, 1024, 2048}; fp32 in ((x0|x1) concatenation when x1 != NULL); out_type 0 = bf16,
- * 1 = fp32, 2 = fp16; optional input-row remap in_row = (r / rows_in) * rows_stride + row_off + r % rows_in and
+ * 1 = fp32, 2 = fp16, 3 (ABI v24; C >= 256, ldo >= 3 C) = fp16 [hi | lo | hi] with hi = fp16(y), lo = fp16(y - hi), the segments C
+ * elements apart: the A' operand of a three-pass GEMM of the x3 precision rung (see iggt_flash_attn_x3_f16_d64); optional input-row remap in_row = (r / rows_in) * rows_stride + row_off + r % rows_in and
  * output-row remap out_row = (r / rows_in) * orows_stride + orow_off + r % rows_in (orows_stride > 0).
  * Replaces nn.LayerNorm at iggt/layers/block.py:84,87, iggt/layers/vision_transformer.py:274,
  * iggt/heads/dpt_head.py:232 and the norms of iggt/heads/window_sa.py (HAB / OCAB / wrapper norms). */
@@ -182,8 +183,36 @@ int iggt_qknorm_rope_f16(const void* qkv, long ld_in, void* q_out, long ldq, voi
                          long v_group_stride, float q_scale, float* qkmax, void* stream);
 
 /* ImageNet-normalise + im2row of 14x14 patches: img fp32 [S][3][H][W] -> bf16 (out_f16 = 0) or fp16 (1)
- * [S*gh*gw][Kpad].  Replaces iggt/models/aggregator.py:206 and the unfold half of iggt/layers/patch_embed.py:75. */
+ * [S*gh*gw][Kpad]; out_f16 = 2 (ABI v24): fp16 [S*gh*gw][3 Kpad] = [hi | lo | hi] (x3 precision rung).  Replaces iggt/models/aggregator.py:206 and the unfold half of iggt/layers/patch_embed.py:75. */
 int iggt_im2row_patch14(const float* img, void* out, int out_f16, int S, int H, int W, int Kpad, void* stream);
+
+/* ---- x3 precision rung of the trunk blocks (ABI v24, round 5; csrc/x3.hip) ------------------------------------------------
+ * Every MFMA operand of an escalated block travels as an fp16 PAIR x = hi + lo (hi = fp16(x), lo = fp16(x - hi): 22 significant
+ * bits) and every product takes three fp16 MFMA passes, a.b ~= a_hi.b_hi + a_lo.b_hi + a_hi.b_lo.  The GEMMs are ordinary
+ * iggt_gemm_f16 calls over a concatenated K axis, A' = [A_hi | A_lo | A_hi] against W' = [W_hi | W_hi | W_lo]; the entry points
+ * below produce the split operands and run the attention on them.
+ *
+ * iggt_qkv_split_f16: qkv fp32 [T][ld_in] (3 x 1024 columns: q | k | v, the fp32 output of the qkv GEMM) -> optional per-head
+ * LayerNorm(64) on q and k (qw / qb / kw / kb, all NULL: none) -> optional 2-D RoPE (cos_t / sin_t fp32 [max_pos + 1][16], both
+ * NULL: none; token t sits at position t % P of its view, the first patch_start positions are un-rotated, the rest a row-major
+ * grid gw wide) -> q multiplied by q_scale (> 0: softmax scale * log2 e) -> fp16 pairs: the hi part of token t at q_out + t * ldq
+ * (1024 columns), the lo part q_lo ELEMENTS behind it; k and v likewise.  Replaces iggt/layers/attention.py:50-58 and
+ * iggt/layers/rope.py:119-188 for escalated blocks. */
+int iggt_qkv_split_f16(const float* qkv, long ld_in, void* q_out, long ldq, long q_lo, void* k_out, long ldk, long k_lo,
+                       void* v_out, long ldv, long v_lo, const float* qw, const float* qb, const float* kw, const float* kb,
+                       const float* cos_t, const float* sin_t, int T, int P, int gw, int patch_start, float eps, float q_scale,
+                       void* stream);
+/* x fp32 [rows][ldx] (N columns, N % 4 == 0) -> act (0 none, 1 exact erf GELU: nn.GELU of iggt/layers/mlp.py:34) -> fp16
+ * out [rows][ldo >= 3 N] = [hi | lo | hi]. */
+int iggt_split3_f16(const float* x, long ldx, void* out, long ldo, int rows, int N, int act, void* stream);
+/* softmax(q k^T) v, head dim 64, token-major like iggt_flash_attn_f16_d64, on fp16 PAIRS: q (already carrying scale * log2 e), k and
+ * v each as a hi and a lo matrix of identical strides.  S in three passes, online max / row sums in fp32, the numerators split
+ * as well, O in three passes; o receives the result as fp16 hi at +0 and, when o_seg > 0, lo at +o_seg and hi again at +2 o_seg
+ * (elements): the A' operand of the proj GEMM.  Replaces F.scaled_dot_product_attention at iggt/layers/attention.py:60-66 for
+ * escalated blocks (48 instead of 16 MFMAs per 32 x 64 score block). */
+int iggt_flash_attn_x3_f16_d64(const void* q, const void* q_lo, const void* k, const void* k_lo, const void* v, const void* v_lo,
+                               void* o, long o_seg, int B, int H, int Nq, int Nk, long q_bs, long q_rs, long k_bs, long k_rs,
+                               long v_bs, long v_rs, long o_bs, long o_rs, void* stream);
 
 /* Tail of the DPT heads on an NHWC fp32 map x [npix][ldx] (32 input channels): 1x1 convolution to Cout (2..8)
  * channels + activate_head: pts [npix][Cout-1] = act(first Cout-1 channels), conf [npix] = conf_act(last channel).

@@ -53,6 +53,15 @@ CASES = {
     "full_s8_518_tlA": (8, 518, 518, "trained_like(qk=0.5,norm=0.5)", 0, 7, 7, 32, 4),
     "full_s8_518_tlB": (8, 518, 518, "trained_like(qk=0.75,norm=0.5)", 0, 7, 7, 32, 4),
     "full_s8_518_tlC": (8, 518, 518, "trained_like", 0, 7, 7, 32, 4),
+    # round 5 (review item 1): the doses BETWEEN tlB and tlC where the reference's fp32 is still well-conditioned (<= 3e-5 from an
+    # fp64 evaluation, profiles/r04_trained_like_sweep.txt) but plain fp16 operands are predicted 3e-3 .. 2e-2 off: the envelope the
+    # per-block precision rung (layers/blocks.py "escalation": hi + lo activation operands, split-q QK^T) is built and gated for.
+    #   tlD  sigma 1 (q/k) / 0.5: sharp global attention (logits of std 15), moderately concentrated LayerNorm scales
+    #   tlE  sigma 0.75 / 0.75
+    #   tlF  sigma 0 / 1: ordinary logits, LayerNorm scales that leave a few dozen of 1 024 channels carrying the signal
+    "full_s8_518_tlD": (8, 518, 518, "trained_like(qk=1,norm=0.5)", 0, 7, 7, 32, 4),
+    "full_s8_518_tlE": (8, 518, 518, "trained_like(qk=0.75,norm=0.75)", 0, 7, 7, 32, 4),
+    "full_s8_518_tlF": (8, 518, 518, "trained_like(qk=0,norm=1)", 0, 7, 7, 32, 4),
 }
 # BASELINE.json configs[0]: REAL photographs (the reference's iggt_demo scenes, copied to tests/golden/images/ as data
 # fixtures) through the reference's OWN loader (iggt/utils/load_fn.py, torchvision.transforms.ToTensor stubbed): every other
@@ -65,10 +74,13 @@ REAL = {
     "real_demo7_s4_336x504_stress": ("demo7", "resize", (504, 336), "stress", 0, 7, 16, 2),
     "real_demo7_s4_crop518_tlA": ("demo7", "crop", None, "trained_like(qk=0.5,norm=0.5)", 0, 7, 16, 2),
     "real_demo7_s4_crop518_tlC": ("demo7", "crop", None, "trained_like", 0, 7, 16, 2),
+    "real_demo7_s4_crop518_tlD": ("demo7", "crop", None, "trained_like(qk=1,norm=0.5)", 0, 7, 16, 2),
+    "real_demo7_s4_crop518_tlE": ("demo7", "crop", None, "trained_like(qk=0.75,norm=0.75)", 0, 7, 16, 2),
+    "real_demo7_s4_crop518_tlF": ("demo7", "crop", None, "trained_like(qk=0,norm=1)", 0, 7, 16, 2),
 }
 IMAGE_DIR = os.path.join(GOLDEN_DIR, "images")
 LARGE = ("full_s8_518_stress", "full_s32_518_stress", "full_s2_1036_stress", "full_s8_518_tlA", "full_s8_518_tlB",
-         "full_s8_518_tlC") + tuple(REAL)
+         "full_s8_518_tlC", "full_s8_518_tlD", "full_s8_518_tlE", "full_s8_518_tlF") + tuple(REAL)
 # The reference's part head evaluates `cross_attention_1` (whose result it discards, part_head.py:178-185) with an explicit
 # softmax over (4g)^2 x (4g)^2 scores per frame and head: 87 616^2 x 8 x 4 B = 245 GB at 1036^2 -- it cannot run here.
 NO_PART = ("full_s2_1036_stress",)
