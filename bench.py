@@ -58,6 +58,10 @@ try:
 except Exception:  # noqa: BLE001
     PMC_TRAFFIC = {}
 FIXTURES = {(32, 518): ("full_s32_518_stress", 8), (8, 518): ("full_s8_518_stress", 7)}   # (views, size) -> (fixture, image seed)
+# --weights <mode>: the heavy-tailed dose fixtures (8 views @ 518^2; iggt_official_amd/synthetic.py "trained_like", oracle/make_golden.py)
+DOSE_FIXTURES = {"trained_like(qk=0.5,norm=0.5)": "full_s8_518_tlA", "trained_like(qk=0.75,norm=0.5)": "full_s8_518_tlB",
+                 "trained_like": "full_s8_518_tlC", "trained_like(qk=1,norm=0.5)": "full_s8_518_tlD",
+                 "trained_like(qk=0.75,norm=0.75)": "full_s8_518_tlE", "trained_like(qk=0,norm=1)": "full_s8_518_tlF"}
 
 
 def usable_cores():
@@ -138,11 +142,11 @@ def cpu_baseline(sample_views, size, budget_s=240):
     return res
 
 
-def output_check(pred, S, H, v0, v1, dev):
+def output_check(pred, S, H, v0, v1, dev, mode="stress"):
     """Compare the timed model's outputs (this rank's views v0:v1) with the reference fixture of this configuration
     (tests/golden/<fixture>.pt: strided samples written by the REFERENCE modules on CPU fp32, oracle/make_golden.py).
     Returns None when no fixture exists for (S, H)."""
-    fx = FIXTURES.get((S, H))
+    fx = FIXTURES.get((S, H)) if mode == "stress" else ((DOSE_FIXTURES[mode], 7) if (mode in DOSE_FIXTURES and (S, H) == (8, 518)) else None)
     path = os.path.join(ROOT, "tests", "golden", (fx[0] if fx else "-") + ".pt")
     if fx is None or not os.path.exists(path):
         return None
@@ -305,6 +309,10 @@ def main():
                     help="developer mode, --gpus 1 only: time what ONE (middle) rank of a W-GPU run computes -- its S / W views, "
                          "the global attention over the keys of all S views (gathers replaced by local copies, "
                          "probes/emulated_shard.py).  The outputs are not the model's; no output check")
+    ap.add_argument("--weights", default="stress", metavar="MODE",
+                    help="synthetic checkpoint mode (iggt_official_amd/synthetic.py): 'stress' (default, the BASELINE configuration) "
+                         "or a heavy-tailed dose such as 'trained_like(qk=1,norm=0.5)' -- what the x3 precision rung costs where it "
+                         "engages (`precision_rung` in the JSON line); with --views 8 the outputs are checked against the dose fixture")
     ap.add_argument("--random-init", action="store_true",
                     help="torch random-init weights and images instead of the synthetic checkpoint (no output check)")
     args = ap.parse_args()
@@ -374,13 +382,13 @@ def main():
         # the CPU values the reference was run with): the timed outputs can be checked against the reference
         with open(os.path.join(ROOT, "tests", "golden", "state_dict_schema.json")) as f:
             schema = json.load(f)
-        sd = synthetic.fill_state_dict(schema, seed=0, mode="stress", device=dev)
+        sd = synthetic.fill_state_dict(schema, seed=0, mode=args.weights, device=dev)
         missing, unexpected = model.load_state_dict(sd, strict=False)
         del sd
         assert not [u for u in unexpected if not u.startswith("track_head.")], unexpected
         iseed = FIXTURES.get((S, H), (None, 1234))[1]
         images = synthetic.make_images(S, H, H, seed=iseed, device=dev)[v0:v1].contiguous()
-        data = "synthetic (seeded hash weights 'stress' seed 0 and hash-noise images, iggt_official_amd/synthetic.py)"
+        data = f"synthetic (seeded hash weights '{args.weights}' seed 0 and hash-noise images, iggt_official_amd/synthetic.py)"
 
     graphs = args.graphs == "on" or (args.graphs == "auto" and (world > 1 or emu))
     if graphs:
@@ -411,6 +419,7 @@ def main():
     fence()
     if not graphs:
         profiling.enable("global_attn")
+        profiling.enable("global_attn_x3")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -422,9 +431,36 @@ def main():
         out = {k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v]) for k, v in out.items()}
         model.enable_graphs(False)
         profiling.enable("global_attn")
+        profiling.enable("global_attn_x3")
         step()
         fence()
     recs = profiling.summarize(profiling.disable("global_attn"))
+    recs_x3 = profiling.summarize(profiling.disable("global_attn_x3") or [])
+    # the precision rung (precision.py "x3"): which blocks run on fp16 operand pairs, and -- one extra forward behind the timed
+    # region with the rung switched off -- what that costs on this checkpoint (nothing on the BASELINE one: no block escalates)
+    rung = model.aggregator.escalation_report()
+    rung = {"blocks": rung["blocks"], "escalated": len(rung["x3"]), "ill_conditioned_by_own_figures": len(rung["own_verdict"]),
+            "escalated_blocks": rung["x3"] if len(rung["x3"]) < rung["blocks"] else "all", "bf16_fallback": rung["bf16_fallback"],
+            "min_participation_ratio": rung["min_participation_ratio"], "max_logit_rms": rung["max_logit_rms"],
+            "thresholds": {"participation_ratio_below": precision.ESC_PR_MIN, "logit_rms_above": precision.ESC_LOGIT_RMS_MAX},
+            "policy": precision.escalation()}
+    if rung["escalated"]:
+        was_graphs = model._graphs_on
+        try:
+            model.enable_graphs(False)
+            precision.set_escalation("off")
+            step()
+            fence()
+            t1 = time.perf_counter()
+            step()
+            fence()
+            rung["ms_per_step_single_fp16_operands"] = (time.perf_counter() - t1) * 1e3
+            rung["single_fp16_output_check"] = None if (args.random_init or emu) else output_check(step(), S, H, v0, v1, dev, args.weights)
+        finally:
+            precision.set_escalation("auto")
+            step()            # re-pack on the rung (the legs below time the shipping configuration)
+            fence()
+            model.enable_graphs(was_graphs)
     soft = model.aggregator.static_softmax_stats() if precision.static_softmax() else None
     # secondary legs, each ONE extra eager forward behind the timed region (the timed steps carry no extra events):
     #   GEMMs (qkv / proj / fc1 / fc2 of the 72 blocks) and head convolutions, HIP events per launch;
@@ -474,7 +510,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert all(torch.isfinite(v).all() for v in out.values() if torch.is_tensor(v))
-    check = None if (args.random_init or emu) else output_check(out, S, H, v0, v1, dev)
+    check = None if (args.random_init or emu) else output_check(out, S, H, v0, v1, dev, args.weights)
     if world > 1 and check is not None:   # worst rank decides
         t = torch.tensor([check["max_l2"]], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -485,15 +521,20 @@ def main():
         P = 5 + (H // 14) ** 2
         C = 1024
         Nq, Nk = (S // (emu or world)) * P, S * P
+        x3_attn = not recs and bool(recs_x3)     # every global block on the x3 rung: its attention kernel is the dominant one
+        if x3_attn:
+            recs = recs_x3
         ms = sum(r[0] for r in recs) / max(len(recs), 1)
         flops = 4.0 * Nq * Nk * C
-        achieved = flops / (ms * 1e-3) / 1e12
+        achieved = flops / (max(ms, 1e-9) * 1e-3) / 1e12
         if (world > 1 or emu) and precision.static_softmax():
             kernel_label = (f"flash_attn_d64_v3_kernel<QB=2,KVM=2,{precision.operand_name()},static-bound> own keys + "
                             f"{(emu or world) - 1} key segments + attn_combine_kernel")
         else:
             kernel_label = _C.attn_kernel_label(1, 16, Nq, Nk, precision.operand_name(), static_bound=precision.static_softmax(),
                                                 with_part_ws=True)
+        if x3_attn:
+            kernel_label = "flash_attn_x3_kernel<f16 hi + lo pairs, 3 MFMA passes per product, online max>"
         traffic = PMC_TRAFFIC.get(f"{S}x{H}x{emu or world}:{kernel_label}", {})
         line = {
             "metric": "views/sec (N-view 518^2 forward)",
@@ -544,6 +585,16 @@ def main():
                                           "input: ~10 us)") if precision.static_softmax() else "one kernel launch",
                          "flops_per_launch": flops},
         }
+        rung["ms_per_step"] = line["ms_per_step"]
+        if x3_attn:
+            line["roofline"]["mfma_equivalent_tflops"] = 3.0 * achieved
+            line["roofline"]["note"] = ("x3 precision rung: `achieved` counts the ALGORITHMIC 4 Nq Nk C once; the kernel issues three "
+                                        "fp16 MFMA passes per product")
+        elif recs_x3:
+            ms3 = sum(r[0] for r in recs_x3) / len(recs_x3)
+            rung["global_attention_x3"] = {"launches": len(recs_x3), "ms_per_launch": ms3,
+                                           "algorithmic_tflops": flops / (ms3 * 1e-3) / 1e12}
+        line["precision_rung"] = rung
         if soft is not None:
             line["static_softmax"] = dict(soft, note="query tiles of the last forward that the static-bound kernel handed to the "
                                           "online-max pass, per block kind (include/iggt_hip.h guard)")

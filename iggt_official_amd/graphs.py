@@ -131,8 +131,18 @@ class GraphCache:
             entry = None
         if entry is None:
             static_in = images.clone()
-            forward(static_in, None)                      # eager warm-up: weight packs, workspaces, RCCL set-up
-            forward(static_in, None)
+            # eager warm-ups: weight packs, workspaces, RCCL set-up -- and the host-side decisions a replay can never revisit
+            # (models/aggregator.py _apply_guard_snapshot: which attention call sites issue the estimated-shift launches).  Each
+            # warm-up is followed by a device synchronisation so that the guard snapshot it ends with HAS landed when the next
+            # one looks at it (back to back the second warm-up started while the device was still running the first, the
+            # snapshot was not there yet, and the captured graph stayed on the round-3 sequence: ADVICE r4); a warm-up that
+            # changed a decision or a buffer (allocation generation moved) is followed by another, up to four.
+            for i in range(4):
+                gen = alloc_generation()
+                forward(static_in, None)
+                torch.cuda.synchronize()
+                if i >= 1 and gen == alloc_generation():
+                    break
             g = SegmentedGraph()
             g.capture(lambda ctl: forward(static_in, ctl))
             self.captures += 1

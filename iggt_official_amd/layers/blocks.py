@@ -129,6 +129,7 @@ def _x3_weight(w: torch.Tensor):
 # FOLD_HI are touched, so ordinary checkpoints pack bit-identically to round 3.  What cannot be folded (rows of qkv's Q / K
 # thirds and of fc1, columns of fc2: a non-linearity follows) and still exceeds the range sends THAT BLOCK to bf16 operands.
 FOLD_HI = 1024.0
+PARTNER_MAX = 1024.0   # largest LayerNorm scale / bias a fold may leave behind (the normalised activations are O(10) x that, in fp16)
 
 
 def _pow2_scale(w: torch.Tensor, dim: int):
@@ -266,11 +267,25 @@ class Block(nn.Module):
             g2 = f32(self.ls2.gamma) if isinstance(self.ls2, LayerScale) else ones()
             n1w, n1b, n2w, n2b = f32(self.norm1.weight), f32(self.norm1.bias), f32(self.norm2.weight), f32(self.norm2.bias)
             folded = 0
+            if dt == torch.float16:
+                raw = float(torch.stack([t.abs().amax() for t in (wq, wp, w1, w2)]).amax())
+                if raw != raw:       # NaN: nothing downstream can be right; say so instead of quietly picking another format
+                    raise ValueError("a transformer block holds NaN weights")
             if dt == torch.float16 and precision.range_folding():
                 # one device-side reduction decides whether anything has to be folded at all (the common case: nothing)
-                if float(torch.stack([t.abs().amax() for t in (wq, wp, w1, w2)]).amax()) > FOLD_HI:
-                    wq, bq, wp, bp, w1, w2, b2, n1w, n1b, n2w, n2b, g1, g2, folded = fold_ranges(
-                        wq, bq, wp, bp, w1, w2, b2, n1w, n1b, n2w, n2b, g1, g2)
+                if raw > FOLD_HI:
+                    unfolded = (wq, bq, wp, bp, w1, w2, b2, n1w, n1b, n2w, n2b, g1, g2)
+                    wq, bq, wp, bp, w1, w2, b2, n1w, n1b, n2w, n2b, g1, g2, folded = fold_ranges(*unfolded)
+                    # the PARTNERS absorb the factors and feed fp16 activations themselves (LayerNorm output = |.| <~ 10 x scale;
+                    # v = LayerNorm output x V rows): a slice that is genuinely large -- its partner NOT correspondingly small --
+                    # would turn them into 1e6 and the stores into +-65504 / the GEMMs into inf.  Then nothing is
+                    # folded: the weights run as stored if they fit fp16, else this block falls to bf16 below.
+                    part = float(torch.stack([t.abs().amax() for t in (n1w, n1b, n2w, n2b)]).amax())
+                    part0 = float(torch.stack([t.abs().amax() for t in (unfolded[7], unfolded[8], unfolded[9], unfolded[10])]).amax())
+                    vmax, vmax0 = float(wq[2 * self.dim:].abs().amax()), float(unfolded[0][2 * self.dim:].abs().amax())
+                    if (part > PARTNER_MAX and part > part0) or (vmax > FOLD_HI and vmax > vmax0):
+                        wq, bq, wp, bp, w1, w2, b2, n1w, n1b, n2w, n2b, g1, g2 = unfolded
+                        folded = 0
             if dt == torch.float16:
                 worst = float(torch.stack([t.abs().amax() for t in (wq, wp, w1, w2)]).amax())
                 if not (worst <= 65504.0):
@@ -381,6 +396,10 @@ class Block(nn.Module):
         guard = pk["guard"] if (static and precision.static_guard()) else None
         if guard is None:
             guard_prev = None
+        # estimated-shift launches (csrc/attention_est.hip) are a one-pass form: a call site that needs them gives up the key-range
+        # split of small grids and, in a view-sharded run, the overlap of the K/V gather with the own-key attention (round 5:
+        # before, a sharded run on adversarial score statistics fell to the online-max kernel on every rank)
+        use_est = guard is not None and self._est_on and precision.attn_estimated_shift() and q_rows_per_wg == 0
         if self.attn.qk_norm:
             assert rope_geom is not None
             qk_args = (pk["qw"], pk["qb"], pk["kw"], pk["kb"], rope_geom["cos"], rope_geom["sin"], T, rope_geom["P"],
@@ -402,7 +421,8 @@ class Block(nn.Module):
                 kv_local = ws.get("kv_local" + alt, (T, 2 * C), dt, dev)
                 _C.qknorm_rope(qkv, qkv, kv_local, kv_local[:, C:], *qk_args, **sk)
                 assert batch == 1
-                if static and q_rows_per_wg == 0 and hasattr(kv_gather, "all_gather_kv_begin") and kv_gather.active:
+                if (static and q_rows_per_wg == 0 and hasattr(kv_gather, "all_gather_kv_begin") and kv_gather.active
+                        and not use_est):
                     overlapped = self._attend_overlapped(qkv, kv_local, kv_gather, qkmax, ao, ws, T, H, C, guard, guard_prev,
                                                          overlap=precision.gather_overlap())
                 else:
@@ -418,10 +438,10 @@ class Block(nn.Module):
             with profiling.region("global_attn" if batch == 1 else "frame_attn", (batch, tokens, Nk)):
                 if static:
                     flags = ws.get("attn_flags", (batch * H * ((tokens + 127) // 128),), torch.int32, dev)
-                    nws = _C.static_attn_ws_bytes(batch, H, tokens, Nk) if q_rows_per_wg == 0 else 0
+                    nws = _C.static_attn_ws_bytes(batch, H, tokens, Nk) if (q_rows_per_wg == 0 and not use_est) else 0
                     part_ws = ws.get("attn_part", (nws,), torch.uint8, dev) if nws else None
                     est_ws = None
-                    if guard is not None and not nws and self._est_on and precision.attn_estimated_shift():
+                    if use_est:
                         est_ws = ws.get("attn_est", (_C.static_attn_est_ws_bytes(batch, H, tokens, Nk),), torch.uint8, dev)
                     # the estimated-shift pre-pass samples the special tokens of every view among the keys: the first
                     # `patch_start` rows of every P rows (frame attention: of the one view; global: of each view)

@@ -197,6 +197,23 @@ class Aggregator(nn.Module):
 
             graphs.buffers_changed()    # captured graphs do not hold the estimated-shift launches of these blocks: re-capture
 
+    def reset_guards(self):
+        """Forget everything the adaptive attention switch has learnt (guard words back to "never measured", estimated-shift
+        launches off, pending snapshot dropped): outputs of the next forwards then do not depend on the inputs this model has seen
+        before -- what golden / determinism fixtures want (INTEGRATION.md "call history")."""
+        from .. import graphs
+
+        self._guard_snap = None
+        fresh = None
+        for b in list(self.frame_blocks) + list(self.global_blocks):
+            g = b.attn_guard()
+            if g is not None:
+                if fresh is None:
+                    fresh = torch.tensor([-1, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=g.device)
+                g.copy_(fresh)
+            b._est_on = False
+        graphs.buffers_changed()     # captured graphs hold the launch sequence of the old decisions
+
     def execution_order(self):
         """The 24 + 48 transformer blocks in the order the forward runs them."""
         order = list(self.patch_embed.blocks)
@@ -221,7 +238,7 @@ class Aggregator(nn.Module):
         conds = [b.own_condition() for b in order]
         packs = [b._packed for b in order]
         return dict(blocks=len(order),
-                    x3=[n for n, b in zip(names, order) if b._x3_request],
+                    x3=[n for n, b, p in zip(names, order, packs) if (p["x3"] if p is not None else bool(b._x3_request))],
                     own_verdict=[n for n, b in zip(names, order) if b.own_escalation()],
                     bf16_fallback=[n for n, p in zip(names, packs) if p is not None and p.get("bf16_fallback")],
                     min_participation_ratio=min(min(c["pr_norm1"], c["pr_norm2"]) for c in conds),

@@ -201,13 +201,22 @@ def set_range_folding(on: bool) -> None:
 #   * predicted r.m.s. of the attention logits from the q/k-norm scales, scale * |g_q * g_k|_2 (1.0 for flat scales; measured
 #     2 / 5.5 / 15 at sigma 0.5 / 0.75 / 1): above ESC_LOGIT_RMS_MAX the softmax is sharp enough that operand rounding of q and k
 #     moves the probabilities by per cent.
-#     (thresholds: the sigma 0.75 / 0.5 fixture -- largest block 5.45, PR >= 0.27 -- passes 1e-3 on single fp16 operands and must
-#     not pay; sigma 1 / 0.5 -- median block 5.0, largest 15 -- does not.)
+# Thresholds, from the dose fixtures measured on the MI355X at 8 x 518^2 / on the demo7 photographs (tests/test_trained_like_gpu.py,
+# profiles/r05_parity_report.json; single fp16 operands -> x3 rung, aggregated tokens, relative l2 against the reference's fp32):
+#     sigma_qk / sigma_n   blocks' PR (min .. max)   logit r.m.s. (median, max)   single fp16         x3
+#     0.5  / 0.5           0.27 .. 0.46              1.5, 2.2                     2.8e-4 / 4.8e-4     -- (not escalated)
+#     0.75 / 0.5           0.27 .. 0.46              2.5, 5.5                     4.0e-4              -- (not escalated)
+#     1    / 0.5           0.27 .. 0.46              5.0, 15.4                    1.0e-3 / 1.5e-3     4.3e-5 / 4.4e-5
+#     0.75 / 0.75          0.055 .. 0.24             2.5, 5.5                     5.0e-4 / 8.0e-4     3.2e-6 / 3.3e-6
+#     0    / 1             0.016 .. 0.125            1.0, 1.05                    1.1e-2 / 6.1e-3     2.8e-5 / 1.5e-5
+#     1    / 1             0.016 .. 0.125            5.0, 15.4                    8.5e-2 / 3.7e-2     2.2e-4 / 8.6e-5
+# ESC_PR_MIN = 0.15 leaves a factor 1.8 to the doses that pass on single operands and trips on most blocks of sigma_n = 0.75
+# (marginal on single operands: 8e-4 on photographs); ESC_LOGIT_RMS_MAX = 7 leaves 28 % to the largest block of sigma_qk = 0.75.
 # An ill-conditioned block AMPLIFIES the rounding of everything upstream of it, so the owner of a block sequence escalates a
 # block when it OR ANY LATER block trips a criterion (plan_escalation below; layers/blocks.py Block._x3_request).
 # IGGT_ESCALATE = auto (default) | off | all;  fp16 operands only (bf16 mode keeps the reference's autocast arithmetic).
-ESC_PR_MIN = 0.25
-ESC_LOGIT_RMS_MAX = 6.0
+ESC_PR_MIN = 0.15
+ESC_LOGIT_RMS_MAX = 7.0
 _escalate = os.environ.get("IGGT_ESCALATE", "auto").lower()
 if _escalate not in ("auto", "off", "all"):
     raise ValueError("IGGT_ESCALATE must be auto, off or all")
@@ -243,6 +252,14 @@ def should_escalate(cond: dict) -> bool:
     if mode != "auto":
         return mode == "all"
     return min(cond["pr_norm1"], cond["pr_norm2"]) < ESC_PR_MIN or cond["logit_rms"] > ESC_LOGIT_RMS_MAX
+
+
+def reset_guards(model) -> None:
+    """Reset the adaptive attention switch of every aggregator inside `model` (models/aggregator.py Aggregator.reset_guards):
+    the outputs of the next forwards no longer depend on the inputs the model has seen before."""
+    for m in model.modules():
+        if m.__class__.__name__ == "Aggregator" and hasattr(m, "reset_guards"):
+            m.reset_guards()
 
 
 def plan_escalation(blocks) -> list:

@@ -78,5 +78,26 @@ def load_checkpoint(model, path_or_state_dict, logger=None, map_location="cpu"):
             log.warning(f"{len(bad)} trunk weight tensors exceed the fp16 range (first: {bad[0]}); switching the trunk to "
                         "bf16 operands (precision.set_operand_dtype): outputs then follow the reference's autocast(bf16) mode")
             precision.set_operand_dtype(torch.bfloat16)
-    return {"loaded": len(aligned), "missing": list(missing), "unexpected": list(unexpected), "max_abs_weight": worst,
-            "beyond_fp16": bad}
+    report = {"loaded": len(aligned), "missing": list(missing), "unexpected": list(unexpected), "max_abs_weight": worst,
+              "beyond_fp16": bad}
+    # round 5: which blocks leave the default arithmetic on THIS checkpoint -- the x3 precision rung (precision.py: blocks that are
+    # ill-conditioned by their own LayerNorm / q-k-norm scales and everything upstream of them run on fp16 operand pairs at ~3x
+    # their MFMA work) and the blocks that fell to bf16 operands (un-foldable weights).  On a GPU-resident model the packs are
+    # built here, so the lists are final; on a CPU-resident one only the escalation plan is (packing happens on the device).
+    agg = getattr(model, "aggregator", None)
+    if agg is not None and hasattr(agg, "plan_escalation"):
+        agg.plan_escalation()
+        if next(agg.parameters()).is_cuda:
+            for blk in agg.execution_order():
+                blk.packed()
+        rep = agg.escalation_report()
+        report.update(escalated_blocks=rep["x3"], ill_conditioned_blocks=rep["own_verdict"], bf16_blocks=rep["bf16_fallback"],
+                      min_participation_ratio=rep["min_participation_ratio"], max_logit_rms=rep["max_logit_rms"])
+        if rep["x3"]:
+            log.warning(f"{len(rep['x3'])} of {rep['blocks']} transformer blocks run on the x3 precision rung (fp16 operand pairs, "
+                        f"~3x their MFMA work): {len(rep['own_verdict'])} are ill-conditioned by their own norm scales "
+                        f"(min participation ratio {rep['min_participation_ratio']:.3f}, max predicted logit r.m.s. "
+                        f"{rep['max_logit_rms']:.1f}); IGGT_ESCALATE=off keeps single fp16 operands")
+        if rep["bf16_fallback"]:
+            log.warning(f"blocks on bf16 operands (weights beyond the fp16 range that no partner can absorb): {rep['bf16_fallback']}")
+    return report

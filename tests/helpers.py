@@ -20,6 +20,9 @@ def build_gpu_model(mode="stress", seed=0, part_on_invalid_grid="skip", include_
     constructor initialisation unless include_track (it only runs when query_points are passed)."""
     key = (mode, seed, part_on_invalid_grid, include_track)
     if key in _MODELS:
+        from iggt_official_amd import precision
+
+        precision.reset_guards(_MODELS[key])    # outputs must not depend on what an earlier test fed this model
         return _MODELS[key]
     from iggt.models.vggt import IGGT
     from oracle import weights

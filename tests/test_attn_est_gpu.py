@@ -223,3 +223,46 @@ def test_workspace_without_guard_keeps_the_norm_bound_kernel(C):
     o2, _, ws2 = _launch(C, qkv, B, H, N, qm, tile=6256, est_mode=1)
     _check(o2, ref, F16)
     assert int(C.static_attn_est_views(ws2, B, H, N)["rowcount"].sum()) == 0
+
+
+@pytest.mark.parametrize("kind", ["noise", "affine", "sinks", "registers"])
+def test_estimated_shift_on_one_rank_of_a_view_sharded_run(C, kind):
+    """Round 5 (review item 3): the per-rank global attention of BASELINE.json configs[3] -- 4 of 32 views' queries (Nq = 5 496)
+    against the gathered keys of all 32 (Nk = 43 968) -- through the ONE-PASS estimated-shift launch that layers/blocks.py issues
+    for a sharded call site whose norm bound flagged tiles (gather first, no key-range split).  Row-sampled fp64 check, the
+    adaptive walk from a fresh guard, and the steady-state time against the norm-bound launch on LayerNorm-of-noise."""
+    B, H, P, S, W, r = 1, 16, 1374, 32, 8, 3
+    Nk, Nq = S * P, S * P // W
+    Cd = H * 64
+    qkv, special = _make(kind, F16, 1, H, Nk, P)
+    qkmax = _qkmax(qkv, 1, H, Nk)
+    q = qkv[r * Nq:(r + 1) * Nq]
+    flags = torch.zeros(H * ((Nq + 127) // 128), dtype=torch.int32, device="cuda")
+    o = torch.full((Nq, Cd), float("nan"), dtype=F16, device="cuda")
+    est_ws = torch.full((C.static_attn_est_ws_bytes(1, H, Nq, Nk),), 0x5A, dtype=torch.uint8, device="cuda")
+    guard = C.new_attn_guard("cuda")
+
+    def launch():
+        C.flash_attn_d64_static(q, qkv[:, Cd:], qkv[:, 2 * Cd:], o, 1, H, Nq, Nk, 0, 3 * Cd, 0, 3 * Cd, 0, 3 * Cd, 0, Cd, qkmax,
+                                flags, 0, None, guard, None, est_ws=est_ws, key_period=P, key_nspecial=5)
+
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    st = guard.tolist()
+    rows = torch.arange(0, Nq, 11, device="cuda")
+    x = qkv.view(Nk, 3, H, 64)
+    ref = _attn_ref(q.view(Nq, 3, H, 64)[rows, 0].transpose(0, 1)[None], x[:, 1].transpose(0, 1)[None], x[:, 2].transpose(0, 1)[None],
+                    0.6931471805599453)[0].transpose(0, 1).reshape(len(rows), Cd)
+    mx, l2 = _check(o[rows], ref, F16)
+    mode = "online-max only" if (st[0] > 0 or st[1] < 0) else ("estimated shift" if st[4] == 1 else "norm bound")
+    report(f"attn_est/rank_of_8_{kind}", dict(max=mx, l2=l2, ms_per_launch=ms, mode=mode, rows_handed_over=st[5],
+                                              tflops=4.0 * Nq * Nk * Cd / (ms * 1e-3) / 1e12))
+    assert mode == ("norm bound" if kind == "noise" else "estimated shift"), (mode, st)

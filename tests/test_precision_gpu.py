@@ -167,3 +167,37 @@ def test_load_state_dict_after_forward_rebuilds_packs():
     for k in ("depth", "depth_conf", "world_points", "world_points_conf", "part_feat"):
         assert torch.equal(b[k], c[k]), k
     assert all(torch.equal(x, y) for x, y in zip(b["pose_enc"], c["pose_enc"]))
+
+
+def test_large_slice_with_an_ordinary_partner_is_not_folded():
+    """a qkv input column that is genuinely 2^22 x larger -- its LayerNorm scale NOT correspondingly small -- is not a
+    re-parametrisation.  Folding it would hand the factor to norm1 (scale 4e6), the fp16 LayerNorm output would saturate and the
+    GEMM turn it into inf.  The fold is refused (partner bound, layers/blocks.py PARTNER_MAX): the block runs on bf16 operands as
+    an un-foldable one does, the others stay on fp16, and every output is finite.  NaN weights raise instead of choosing a format."""
+    from iggt_official_amd import precision
+    from oracle import weights
+
+    model = build_gpu_model("stress", 0)
+    sd = weights.fill_state_dict(schema(), seed=0, mode="stress", device="cuda")
+    key = "aggregator.global_blocks.2.attn.qkv.weight"
+    good = sd[key].clone()
+    try:
+        sd[key][:, 5] *= 2.0 ** 22
+        model.load_state_dict(sd, strict=False)
+        out = model(_tiny_inputs())
+        torch.cuda.synchronize()
+        for k, v in out.items():
+            if torch.is_tensor(v):
+                assert torch.isfinite(v).all(), k
+        pk = model.aggregator.global_blocks[2].packed()
+        assert pk["folded_slices"] == 0 and pk["w_qkv"].dtype == torch.bfloat16 and pk["bf16_fallback"]
+        assert model.aggregator.global_blocks[3].packed()["w_qkv"].dtype == torch.float16
+        assert "global_blocks.2" in model.aggregator.escalation_report()["bf16_fallback"]
+        sd[key] = good.clone()
+        sd[key][0, 0] = float("nan")
+        model.load_state_dict(sd, strict=False)
+        with pytest.raises(ValueError, match="NaN"):
+            model(_tiny_inputs())
+    finally:
+        sd[key] = good
+        model.load_state_dict(sd, strict=False)

@@ -8,7 +8,7 @@ loader's crop-518, in three doses (the dose-response table is profiles/r04_train
 
   tlA  sigma 0.5 (q/k-norm) / 0.5 (norm1/2): the heaviest tails at which the reference's OWN bf16 autocast mode still tracks its
        fp32 path to < 1e-2 -- global-attention logits of std 2, max 8-10, mean top probability 0.3.  Gated at north_star's 1e-3.
-  tlB  sigma 0.75 / 0.5: past that edge (the fp16-operand simulation WITHOUT mean compensation reads 1.2e-3).  Gated at 3e-3, reported.
+  tlB  sigma 0.75 / 0.5: past that edge (the fp16-operand simulation WITHOUT mean compensation reads 1.2e-3).  Gated at 1e-3 (round 5; measured 4.6e-4), no block escalated.
   tlC  the review's literal recipe, sigma 1 / 1: logits of std 15, max 88 -- a near-argmax softmax.  The map is ill-conditioned as a
        function of its own weights: the reference's fp32 arithmetic sits 8e-4 from an fp64 evaluation of the same restatement, its
        bf16 mode 0.56.  No 16-bit operand path can meet 1e-3 against it; the numbers are reported, outputs must be finite, and the
@@ -60,9 +60,13 @@ def _run(case, warm=3):
         model(images)
         torch.cuda.synchronize()     # the guard snapshot of this forward has landed before the next one looks at it
     profiling.enable("global_attn")
+    profiling.enable("global_attn_x3")
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
     pred = model(images)
+    t1.record()
     torch.cuda.synchronize()
-    recs = profiling.summarize(profiling.disable("global_attn"))
+    recs = profiling.summarize(profiling.disable("global_attn")) + profiling.summarize(profiling.disable("global_attn_x3"))
     h.remove()
     ss, ts, cs = m["spatial_stride"], m["token_stride"], m.get("channel_stride", 1)
     res = {f"tokens_{li}": errors(cap["tokens"][li][:, :, ::ts, ::cs], g[f"tokens_{li}"]) for li in (4, 11, 17, 23)}
@@ -73,12 +77,18 @@ def _run(case, warm=3):
         if torch.is_tensor(v):
             assert torch.isfinite(v).all(), (case, k)
     att = model.aggregator.static_softmax_stats()
-    guards = [b.attn_guard().tolist() for b in model.aggregator.global_blocks]
-    att["global_mode_per_block"] = "".join("o" if gd[1] < 0 else ("e" if gd[4] == 1 else "n") for gd in guards)
-    att["global_rows_redone"] = sum(max(gd[5], 0) for gd in guards)
+    guards = [None if b.attn_guard() is None else b.attn_guard().tolist() for b in model.aggregator.global_blocks]
+    # per global block: x = x3 precision rung (pairs, online maximum), o = online-max only, e = estimated shift, n = norm bound
+    att["global_mode_per_block"] = "".join("x" if gd is None else "o" if gd[1] < 0 else ("e" if gd[4] == 1 else "n") for gd in guards)
+    att["global_rows_redone"] = sum(max(gd[5], 0) for gd in guards if gd is not None)
+    esc = model.aggregator.escalation_report()
+    att["escalated_blocks"] = len(esc["x3"])
+    att["escalation"] = dict(own_verdict=len(esc["own_verdict"]), bf16_fallback=esc["bf16_fallback"],
+                             min_participation_ratio=esc["min_participation_ratio"], max_logit_rms=esc["max_logit_rms"])
     att["global_attn_ms_per_block"] = [round(r[0], 4) for r in recs]
     att["global_attn_ms_mean"] = sum(r[0] for r in recs) / max(len(recs), 1)
     att["tokens"] = m["S"] * (5 + (m["H"] // 14) * (m["W"] // 14))
+    att["forward_ms"] = t0.elapsed_time(t1)
     return res, att, cap["tokens"]
 
 
@@ -113,28 +123,111 @@ def test_trained_like_dose_b_reported():
     _report("full_s8_518_tlB", res, att)
     # the host-side snapshot turned the estimated-shift launches on where the norm bound had flagged tiles, and they stuck
     assert att["global_mode_per_block"].count("e") >= 12, att["global_mode_per_block"]
+    assert att["escalated_blocks"] == 0, att          # passes on single fp16 operands and must not pay for the x3 rung
     for k, v in res.items():
-        assert v[1] < 3e-3, (k, v)
+        assert v[1] < 1e-3, (k, v)
+
+
+# Round 5 (review item 1): the doses between tlB and tlC.  The reference's fp32 is well-conditioned there (<= 3e-5 from an fp64
+# evaluation, profiles/r04_trained_like_sweep.txt) while single fp16 operands are predicted 3e-3 .. 2e-2 off -- and leave-one-in
+# ablation shows no single rounding site carrying it (profiles/r05_precision_groups.txt).  The x3 precision rung (csrc/x3.hip,
+# precision.plan_escalation) runs every block that is ill-conditioned by its own LayerNorm / q-k-norm scales, and every block in
+# front of it, on fp16 hi + lo operand pairs (three MFMA passes per product).
+#   tlD  sigma 1 / 0.5: global-attention logits of std 15 (sharp softmax), LayerNorm scales as in tlA
+#   tlE  sigma 0.75 / 0.75
+#   tlF  sigma 0 / 1: ordinary logits; ~19 of 1 024 channels carry the normalised signal
+@pytest.mark.parametrize("case", ["full_s8_518_tlD", "full_s8_518_tlE", "full_s8_518_tlF", "real_demo7_s4_crop518_tlD",
+                                  "real_demo7_s4_crop518_tlE", "real_demo7_s4_crop518_tlF"])
+def test_heavy_tailed_well_conditioned_doses_meet_the_tolerance_on_the_x3_rung(case):
+    """Gated at north_star's 1e-3 like every bounded-uniform fixture; the same forward with the rung switched off is run and
+    REPORTED (what single fp16 operands give at this dose, and what the rung costs)."""
+    from iggt_official_amd import precision
+
+    precision.set_escalation("off")
+    try:
+        res_off, att_off, _ = _run(case, warm=2)
+    finally:
+        precision.set_escalation("auto")
+    res, att, _ = _run(case, warm=1)
+    _report(case, res, att, dict(single_fp16_operands=dict(
+        errors={k: dict(max=v[0], l2=v[1]) for k, v in res_off.items()}, forward_ms=att_off["forward_ms"],
+        global_mode_per_block=att_off["global_mode_per_block"])))
+    assert att["escalated_blocks"] > 0, att
+    for k, v in res.items():
+        assert v[1] < 1e-3, (case, k, v)
+        if not k.startswith("tokens"):
+            assert v[0] < 2e-3, (case, k, v)
 
 
 @pytest.mark.parametrize("case", ["full_s8_518_tlC", "real_demo7_s4_crop518_tlC"])
-def test_trained_like_literal_recipe_is_reported_not_gated(case):
-    """The review's literal recipe (sigma 1 / 1, tokens 30x, 8x columns).  Reported; see the module docstring for why 1e-3 is
-    not a meaningful gate here.  What must hold: finite outputs, tokens that are not garbage (the fp16-rounding simulation on the
-    CPU predicts 0.3-0.4), and a kernel choice inside the attention dispatcher (adaptive static / estimated / online-max vs
-    online-max for every block) that moves the tokens no more than the distance to the reference -- two rounding differences
-    amplified by the same weights; a kernel fault would show as a much larger one."""
+def test_trained_like_literal_recipe_on_the_x3_rung(case):
+    """The round-3 review's literal recipe (sigma 1 / 1, tokens 30x, 8x columns): the map is ill-conditioned as a function of its own
+    weights -- the reference's fp32 arithmetic itself sits 7.8e-4 from an fp64 evaluation (its bf16 mode 0.56), so 1e-3 against
+    the fp32 fixture is the noise floor of the REFERENCE, not a property of this path.  Single fp16 operands measured 8.3e-2
+    (8 views) / 3.6e-2 (photographs) in round 4; on the x3 rung every block runs on operand pairs and the distance is gated at
+    TLC_GATE -- a few times the reference's own distance from fp64 (two fp32-grade evaluations in different summation orders).
+    The single-fp16 forward is still run and reported; with the 8-view case also the dispatcher's kernel choice (adaptive static /
+    estimated / online-max vs online-max everywhere), which must not move the tokens more than the operand rounding does."""
     from iggt_official_amd import precision
 
-    res, att, tok = _run(case)
-    tok23 = tok[23].clone()
-    precision.set_static_softmax(False)
+    res, att, _ = _run(case, warm=1)
+    precision.set_escalation("off")
     try:
-        res_on, _, tok_on = _run(case, warm=0)
+        res_off, att_off, tok = _run(case)
+        extra = dict(single_fp16_operands=dict(errors={k: dict(max=v[0], l2=v[1]) for k, v in res_off.items()},
+                                               global_mode_per_block=att_off["global_mode_per_block"],
+                                               forward_ms=att_off["forward_ms"]))
+        if case.startswith("full"):
+            tok23 = tok[23].clone()
+            precision.set_static_softmax(False)
+            try:
+                res_on, _, tok_on = _run(case, warm=0)
+            finally:
+                precision.set_static_softmax(True)
+            kernel_choice = errors(tok23, tok_on[23])
+            extra["single_fp16_operands"].update(tokens_23_l2_online_max_only=res_on["tokens_23"][1],
+                                                 tokens_23_l2_between_dispatch_modes=kernel_choice[1])
+            assert kernel_choice[1] < 2.0 * res_off["tokens_23"][1] + 1e-3, (kernel_choice, res_off["tokens_23"])
     finally:
-        precision.set_static_softmax(True)
-    kernel_choice = errors(tok23, tok_on[23])
-    _report(case, res, att, dict(tokens_23_l2_online_max_only=res_on["tokens_23"][1],
-                                 tokens_23_l2_between_dispatch_modes=kernel_choice[1]))
-    assert res["tokens_23"][1] < 0.8, res["tokens_23"]
-    assert kernel_choice[1] < 2.0 * res["tokens_23"][1] + 1e-3, (kernel_choice, res["tokens_23"])
+        precision.set_escalation("auto")
+    _report(case, res, att, extra)
+    assert att["escalated_blocks"] == 72, att
+    assert res_off["tokens_23"][1] < 0.8, res_off["tokens_23"]
+    for k, v in res.items():
+        assert v[1] < TLC_GATE, (case, k, v)
+
+
+TLC_GATE = 1e-3     # measured: tokens 2.2e-4 (8 views) / 8.6e-5 (photographs), outputs <= 3.6e-4 (profiles/r05_parity_report.json)
+
+
+def test_graph_capture_takes_the_estimated_shift_decision():
+    """under enable_graphs() the host-side decision to issue the estimated-shift launches used to miss the capture -- the
+    two warm-up forwards ran back to back, the guard snapshot of the first had not landed when the second looked, and the captured
+    graph stayed on the round-3 sequence (flagged tiles redone by the online-max kernel).  graphs.GraphCache.run now synchronises
+    between warm-ups and repeats them while decisions change: on the sigma 0.75 / 0.5 checkpoint the REPLAYED forward runs at
+    least half of its global blocks in estimated mode, hands nothing to whole-tile redo, and meets the tolerance."""
+    from iggt_official_amd import precision
+
+    g = load_golden("full_s8_518_tlB")
+    m = g["meta"]
+    model = build_gpu_model(m["mode"], m["weight_seed"])
+    precision.reset_guards(model)
+    images = _images(g, m)
+    model.enable_graphs(True)
+    try:
+        model(images)                 # warm-ups + capture + first replay
+        pred = model(images)          # replay
+        torch.cuda.synchronize()
+        guards = [b.attn_guard().tolist() for b in model.aggregator.global_blocks]
+        modes = "".join("o" if gd[1] < 0 else ("e" if gd[4] == 1 else "n") for gd in guards)
+        report("trained_like/full_s8_518_tlB_graphs", dict(global_mode_per_block=modes,
+                                                           flagged_tiles=[gd[1] for gd in guards]))
+        assert modes.count("e") >= 12, modes
+        assert all(gd[1] == 0 for gd in guards if gd[4] == 1), guards     # estimated mode: no whole tile handed over
+        ss = m["spatial_stride"]
+        for k in KEYS:
+            e = errors(pred[k][:, :, ::ss, ::ss], g[k])
+            assert e[1] < 1e-3, (k, e)
+    finally:
+        model.enable_graphs(False)
+        precision.reset_guards(model)
