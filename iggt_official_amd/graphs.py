@@ -122,7 +122,10 @@ class GraphCache:
     def reset(self):
         self._graphs.clear()
 
-    def run(self, key, images: torch.Tensor, forward: Callable[[torch.Tensor, SegmentedGraph], object]):
+    def run(self, key, images: torch.Tensor, forward: Callable[[torch.Tensor, SegmentedGraph], object],
+            fixed_warmups: int = 0):
+        """fixed_warmups > 0: exactly that many eager warm-up forwards in front of a capture.  A view-sharded run needs it: every
+        forward issues collectives, so all ranks must run the SAME number of them, while "did a decision change" is rank-local."""
         entry = self._graphs.get(key)
         if entry is not None and entry[2] != alloc_generation():
             # some buffer this graph may point into was reallocated since the capture: every entry of that age is unsafe
@@ -137,11 +140,11 @@ class GraphCache:
             # one looks at it (back to back the second warm-up started while the device was still running the first, the
             # snapshot was not there yet, and the captured graph stayed on the round-3 sequence: ADVICE r4); a warm-up that
             # changed a decision or a buffer (allocation generation moved) is followed by another, up to four.
-            for i in range(4):
+            for i in range(fixed_warmups or 4):
                 gen = alloc_generation()
                 forward(static_in, None)
                 torch.cuda.synchronize()
-                if i >= 1 and gen == alloc_generation():
+                if not fixed_warmups and i >= 1 and gen == alloc_generation():
                     break
             g = SegmentedGraph()
             g.capture(lambda ctl: forward(static_in, ctl))

@@ -425,6 +425,14 @@ class Block(nn.Module):
                         and not use_est):
                     overlapped = self._attend_overlapped(qkv, kv_local, kv_gather, qkmax, ao, ws, T, H, C, guard, guard_prev,
                                                          overlap=precision.gather_overlap())
+                elif (static and q_rows_per_wg == 0 and hasattr(kv_gather, "all_gather_kv_begin") and kv_gather.active):
+                    # a sharded call site on the estimated shift: gather first, then the one-pass launch below.  The SAME two
+                    # collectives as the overlapped form (K/V rows, then the 32 norm maxima) -- `use_est` is a rank-LOCAL decision
+                    # (each rank's own guard words), and ranks that disagree on it must still issue identical collectives; the
+                    # gathered maxima also give the key bound over all ranks without a pass over the gathered rows
+                    kv_all, stats_all = kv_gather.all_gather_kv(kv_local, qkmax[:32])
+                    qkmax[16:32].copy_(stats_all[:, 16:32].amax(0))
+                    k_src, v_src, kv_rs, Nk, k_bs = kv_all, kv_all[:, C:], 2 * C, kv_all.shape[0], 0
                 else:
                     kv_all = gather(kv_local)
                     k_src, v_src, kv_rs, Nk, k_bs = kv_all, kv_all[:, C:], 2 * C, kv_all.shape[0], 0

@@ -104,7 +104,8 @@ class _Base(nn.Module, PyTorchModelHubMixin):
                 if shard is not None:
                     shard.ctl = None
 
-        return self._gcache.run(key, images, fwd)
+        # sharded: a rank-uniform number of warm-up forwards (each issues collectives; graphs.GraphCache.run)
+        return self._gcache.run(key, images, fwd, fixed_warmups=3 if (shard is not None and shard.active) else 0)
 
     def _common(self, images, query_points):
         if images.dim() == 4:

@@ -309,3 +309,79 @@ def test_hdbscan_timing_report():
         dt = time.perf_counter() - t0
         report(f"post/hdbscan/timing_{M}", dict(points=M, seconds=dt, clusters=int(got.max() + 1), noise=int((got < 0).sum())))
         assert got.max() + 1 == 8
+
+
+def test_hdbscan_at_1_35_million_points_is_checked_not_only_timed():
+    """Round 5 (review housekeeping): the estimator at the size of the demo's largest call (4 views x 504 x 672 = 1 354 752 pixels,
+    8 channels), CHECKED.  scikit-learn cannot run this size in a test (204 s at 169 k points), so the check is made of exact
+    properties every minimum spanning tree of the mutual-reachability graph has, verified by brute force on random samples, plus
+    the planted partition:
+      (a) core distances of 2 048 sampled points = the k-th smallest of their 1.35 M brute-force distances;
+      (b) the tree has M - 1 edges, every edge weight equals max(core_u, core_v, |x_u - x_v|) of its endpoints;
+      (c) for 2 048 sampled points u: the lightest tree edge at u has the weight of u's lightest mutual-reachability edge to ANY
+          other point (brute force over all 1.35 M) -- the lightest edge at every vertex belongs to the tree (cut property), so a
+          pruning rule that skipped a tile it should have searched shows up here;
+      (d) the tree is connected (a union-find over its edges ends in one component);
+      (e) the labels recover the 8 planted clusters exactly (adjusted Rand index 1 over the non-noise pixels, no cluster missing)."""
+    import time
+
+    from conftest import report
+    from sklearn.metrics import adjusted_rand_score
+
+    from iggt_official_amd.utils import hdbscan as hd
+
+    rng = np.random.default_rng(5)
+    M, k = 1_354_752, 100
+    X = _blobs(rng, M, 8, 8, 0.05)
+    planted = np.repeat(np.arange(8), M // 8)
+    x = torch.from_numpy(X).cuda()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eu, ev, ew, core = hd.mutual_reachability_mst(x, k)
+    torch.cuda.synchronize()
+    t_mst = time.perf_counter() - t0
+    assert eu.numel() == M - 1
+    # (b)
+    d_uv = (x[eu] - x[ev]).double().norm(dim=1)
+    mr = torch.maximum(torch.maximum(core[eu], core[ev]).double(), d_uv)
+    assert torch.allclose(ew.double(), mr, rtol=3e-6, atol=1e-7), float((ew.double() - mr).abs().max())
+    # (a) + (c), brute force in chunks of 256 sampled rows against all points
+    g = torch.Generator(device="cuda").manual_seed(7)
+    sample = torch.randperm(M, generator=g, device="cuda")[:2048]
+    x64 = x.double()
+    lightest = torch.full((M,), float("inf"), dtype=torch.float64, device="cuda")
+    lightest.scatter_reduce_(0, eu, ew.double(), "amin")
+    lightest.scatter_reduce_(0, ev, ew.double(), "amin")
+    worst_core, worst_edge = 0.0, 0.0
+    for c0 in range(0, sample.numel(), 256):
+        idx = sample[c0:c0 + 256]
+        D = torch.cdist(x64[idx], x64)                                  # [256, M] exact distances
+        kth = torch.topk(D, k, dim=1, largest=False).values[:, k - 1]
+        worst_core = max(worst_core, float((core[idx].double() - kth).abs().max() / kth.max()))
+        MR = torch.maximum(torch.maximum(kth[:, None], core.double()[None, :]), D)
+        MR[torch.arange(idx.numel(), device="cuda"), idx] = float("inf")
+        best = MR.amin(1)
+        worst_edge = max(worst_edge, float(((lightest[idx] - best).abs() / best).max()))
+        del D, MR
+    assert worst_core < 3e-6 and worst_edge < 3e-6, (worst_core, worst_edge)
+    # (d) connectivity by pointer jumping over the edge list
+    parent = torch.arange(M, device="cuda")
+    for _ in range(64):
+        lo = torch.minimum(parent[eu], parent[ev])
+        parent.scatter_reduce_(0, eu, lo, "amin")
+        parent.scatter_reduce_(0, ev, lo, "amin")
+        nxt = parent[parent]
+        if torch.equal(nxt, parent) and bool((parent[eu] == parent[ev]).all()):
+            break
+        parent = nxt
+    assert int(torch.unique(parent).numel()) == 1
+    # (e)
+    t0 = time.perf_counter()
+    got = hd.hdbscan_labels(x, 500, k, 0.06)
+    t_all = time.perf_counter() - t0
+    keep = got >= 0
+    ari = adjusted_rand_score(planted[keep], got[keep])
+    report("post/hdbscan/checked_1354752", dict(points=M, mst_seconds=t_mst, labels_seconds=t_all, clusters=int(got.max() + 1),
+                                               noise=int((~keep).sum()), ari_vs_planted=ari, core_rel_err_sampled=worst_core,
+                                               lightest_edge_rel_err_sampled=worst_edge, rounds=hd.LAST_STATS.get("components_per_round")))
+    assert got.max() + 1 == 8 and ari == 1.0 and (~keep).sum() < M // 100
