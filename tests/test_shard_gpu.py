@@ -111,6 +111,11 @@ def _worker(rank, world, port, case, kv_groups, graphs, overlap, ret, backend="g
         else:
             res["pose_enc"] = errors(torch.stack(pred["pose_enc"], 0), g["pose_enc"])[1]   # all views on every rank
         ret[rank] = res
+        # quiesce before the process group goes away: graph objects and pending asynchronous works are dropped while the RCCL
+        # watchdog thread may still be polling their events
+        model.reset_graphs()
+        model.set_view_shard(None)
+        torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
 
@@ -135,14 +140,16 @@ def test_two_rank_sharded_forward_matches_reference(case, kv_groups, graphs, ove
             assert l2 < 1e-3, (rank, k, l2)   # same gate as the unsharded run (fp16 operands)
 
 
-@pytest.mark.parametrize("world,graphs,overlap", [(8, True, True), (8, False, False), (4, True, False)])
+@pytest.mark.parametrize("world,graphs,overlap", [(8, True, True), (4, False, False)])
 def test_many_rank_sharded_forward_at_518(world, graphs, overlap):
     """BASELINE.json configs[3]'s machinery with more than two ranks, end to end against the reference: 8 views @ 518^2
     (fixture full_s8_518_stress, produced by the reference modules at this size) over 8 ranks x 1 view and 4 ranks x 2 views,
     all on cuda:0 over gloo.  Every rank runs the product's sharded forward -- own-key launch, ONE segment-mode launch over the
     7 (3) foreign key segments under each segment's own gathered key bound, combine kernel with per-rank shifts, camera-token
-    gather over all ranks -- in the overlapped and the gather-first form, eagerly and as hipGraph segments (the fourth
-    combination, 4 ranks overlapped eager, ran green in round 4 and was dropped to keep the GPU suite inside its time limit).  Gates: the
+    gather over all ranks -- 8 ranks overlapped as hipGraph segments, 4 ranks gather-first eagerly (8 ranks gather-first eager,
+    4 ranks gather-first as graph segments and 4 ranks overlapped eager ran green in rounds 4 / 5 and were dropped to keep the GPU
+    suite inside its time budget: a many-rank graph run costs ~100 s of process start-up and gloo copies; gather-first + graphs
+    stays covered at two ranks, gather-first at 8 ranks by test_sharded_forward_on_heavy_tailed_checkpoints).  Gates: the
     unsharded ones (1e-3 l2) on every rank's slice of depth / depth_conf / world_points / world_points_conf, on pose_enc (all
     views on every rank), on the four token layers and on the special-token rows; rank 0 alone may use slot 0 of the
     camera / register tokens (asserted inside the worker at the call site)."""
@@ -179,14 +186,15 @@ def test_rccl_world_of_one(kv_groups, graphs, overlap):
         assert l2 < 1e-3, (k, l2)
 
 
-@pytest.mark.parametrize("case,world,graphs,warm", [("full_s8_518_tlB", 8, True, 3), ("full_s8_518_tlD", 4, False, 0)])
+@pytest.mark.parametrize("case,world,graphs,warm", [("full_s8_518_tlB", 8, False, 3), ("full_s8_518_tlD", 4, False, 0)])
 def test_sharded_forward_on_heavy_tailed_checkpoints(case, world, graphs, warm):
     """Round 5 (review item 3): the sharded path where the norm bound of the static softmax is loose / where the x3 precision rung
     engages, end to end against the reference fixtures on cuda:0 over gloo.
       full_s8_518_tlB, 8 ranks x 1 view: trained-like q/k-norm scales (sigma 0.75) -- after the warm-up forwards most global blocks
         run the ONE-PASS estimated-shift launch on the gathered keys (round 4: every rank fell to the online-max kernel).  Whether a
         rank switches a block is that rank's own decision; both forms issue the same two collectives, so ranks that disagree stay
-        in step -- here also under hipGraph capture, whose warm-up count is fixed for sharded runs.
+        in step (this case also ran green under hipGraph capture, 131 s; the fixed warm-up count of sharded captures is exercised
+        by test_many_rank_sharded_forward_at_518[8-True-True]).
       full_s8_518_tlD, 4 ranks x 2 views: 71 of 72 blocks on the x3 rung; K and V pairs travel as one [T_local, 4C] message.
     Gates: the unsharded ones on every rank's slice."""
     from conftest import report
