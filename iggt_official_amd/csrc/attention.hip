@@ -66,7 +66,7 @@ int fill_params(AttnParams& p, const void* q, const void* k, const void* v, void
     p.scale_log2 = 1.f; p.qtiles = 0; p.qkmax = nullptr; p.flags = nullptr; p.static_min_l = 0.f;
     p.ksplit = 0; p.slot0 = 0; p.seg_len = 0; p.skip_seg = -1; p.seg_kmax = nullptr; p.o_part = nullptr; p.l_part = nullptr; p.c_part = nullptr;
     p.guard = nullptr; p.guard_prev = nullptr; p.guard_retry = GUARD_RETRY_DEFAULT;
-    p.est_ws = nullptr; p.est_force = 0;
+    p.est_ws = nullptr; p.est_force = 0; p.list_mode = 0;
     return 0;
 }
 

@@ -110,7 +110,9 @@ IGGT_DEVINL void guard_update(const AttnParams& p, int nwork, int rows_per_item,
         nrows = red[4] + red[5] + red[6] + red[7];
         const int g0 = p.guard[0];
         const bool skipped = guard_skips(p.guard, p.guard_prev);
-        int mode = guard_mode(p);
+        // a launch WITHOUT the estimated-shift workspace (partial / combine path, key-range split) runs the norm bound whatever
+        // the word says: it must not reset the mode the call site's one-pass launches have settled in
+        int mode = p.est_ws != nullptr ? guard_mode(p) : p.guard[4];
         int g;
         if (skipped) {
             g = (g0 < 0 ? p.guard_retry : g0) - 1;                    // this call ran the online-max kernel only: count down

@@ -72,6 +72,9 @@ class ViewShard:
         n = 1
         for s in shape:
             n *= s
+        # keyed by (name, dtype): a block that fell to bf16 operands beside fp16 neighbours (layers/blocks.py) must not make
+        # the shared buffer flip its dtype -- and with it reallocate and invalidate every captured graph -- twice per forward
+        name = (name, like.dtype)
         cur = self._bufs.get(name)
         if cur is None or cur.numel() < n or cur.dtype != like.dtype or cur.device != like.device:
             if cur is not None:

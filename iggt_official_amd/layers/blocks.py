@@ -108,6 +108,21 @@ def _h16_residual(w: torch.Tensor, dt: torch.dtype):
     return (w - w.to(dt).float()).to(dt).contiguous()
 
 
+GEMM_MAX_OPERAND_ELEMENTS = 1 << 31   # csrc/gemm_bf16_t256.hip, gemm_bf16_duo.hip: M x lda and N x ldw below this
+
+
+def _gemm_rows(a, w, out, **kw):
+    """_C.gemm_h16 over row chunks when M x lda would leave the 32-bit operand offsets of the LDS-DMA kernels (the K = 3 x 4 096
+    GEMM of the x3 rung at 64 views @ 1036^2: 350 784 rows x 12 288 columns); rows are independent, the chunks run back to back."""
+    M, lda = a.shape[0], a.stride(0)
+    if M * lda < GEMM_MAX_OPERAND_ELEMENTS:
+        return _C.gemm_h16(a, w, out, **kw)
+    step = max(256, (GEMM_MAX_OPERAND_ELEMENTS - 1) // lda // 256 * 256)
+    for r0 in range(0, M, step):
+        _C.gemm_h16(a[r0:r0 + step], w, out[r0:r0 + step], **kw)
+    return out
+
+
 def _x3_weight(w: torch.Tensor):
     """W' = [W_hi | W_hi | W_lo] (fp16, [N, 3 K]) for the three-pass GEMM of the x3 precision rung against A' = [A_hi | A_lo | A_hi]
     (csrc/x3.hip): A W^T ~= A_hi W_hi^T + A_lo W_hi^T + A_hi W_lo^T."""
@@ -514,7 +529,7 @@ class Block(nn.Module):
         qkv32 = ws.get("x3_qkv32", (T, 3 * C), torch.float32, dev)
         _C.layernorm(x2d, pk["n1w"], pk["n1b"], xn3, self.norm1.eps, split3=True)
         with profiling.region("gemm", ("qkv_x3", T, 3 * C, 3 * C)):
-            _C.gemm_h16(xn3, pk["w3_qkv"], qkv32, bias=pk["b_qkv"])
+            _gemm_rows(xn3, pk["w3_qkv"], qkv32, bias=pk["b_qkv"])
         q_scale = self.attn.scale * _C.LOG2E
         norm = dict(qw=pk["qw"], qb=pk["qb"], kw=pk["kw"], kb=pk["kb"], eps=self.attn.q_norm.eps) if self.attn.qk_norm else {}
         rope = {}
@@ -546,15 +561,15 @@ class Block(nn.Module):
             _C.flash_attn_x3(q, q_lo, k, k_lo, v, v_lo, ao3, C, batch, H, tokens, Nk, q_bs, q_rs, k_bs, kv_rs, k_bs, kv_rs,
                              tokens * 3 * C, 3 * C)
         with profiling.region("gemm", ("proj_x3", T, C, 3 * C)):
-            _C.gemm_h16(ao3, pk["w3_proj"], x2d, bias=pk["b_proj"], gamma=pk["g1"], accumulate=True)
+            _gemm_rows(ao3, pk["w3_proj"], x2d, bias=pk["b_proj"], gamma=pk["g1"], accumulate=True)
         _C.layernorm(x2d, pk["n2w"], pk["n2b"], xn3, self.norm2.eps, split3=True)
         h32 = ws.get("x3_h32", (T, Hd), torch.float32, dev)
         with profiling.region("gemm", ("fc1_x3", T, Hd, 3 * C)):
-            _C.gemm_h16(xn3, pk["w3_fc1"], h32, bias=pk["b_fc1"])
+            _gemm_rows(xn3, pk["w3_fc1"], h32, bias=pk["b_fc1"])
         hid3 = ws.get("x3_hid", (T, 3 * Hd), f16, dev)
         _C.split3(h32, hid3, act=1)
         with profiling.region("gemm", ("fc2_x3", T, C, 3 * Hd)):
-            _C.gemm_h16(hid3, pk["w3_fc2"], x2d, bias=pk["b_fc2"], gamma=pk["g2"], accumulate=True)
+            _gemm_rows(hid3, pk["w3_fc2"], x2d, bias=pk["b_fc2"], gamma=pk["g2"], accumulate=True)
         return x2d
 
     def _attend_overlapped(self, qkv, kv_local, shard, qkmax, ao, ws, T, H, C, guard=None, guard_prev=None, overlap=True):

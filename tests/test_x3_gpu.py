@@ -247,3 +247,27 @@ def test_block_x3_against_fp64():
             precision.set_escalation("auto")
     report("x3/block_vs_fp64", dict(l2_x3=res["all"], l2_single_fp16=res["off"]))
     assert res["all"] < 2e-5 and res["all"] < res["off"] / 20, res
+
+
+def test_gemm_row_chunks_equal_one_launch(C):
+    """layers/blocks.py _gemm_rows: above the 32-bit operand-offset limit of the LDS-DMA GEMMs (the K = 12 288 GEMM of the rung at
+    64 views @ 1036^2) the rows go in chunks; here the limit is lowered so that a small problem takes the chunked path."""
+    from iggt_official_amd.layers import blocks
+
+    M, N, K = 5000, 1024, 768
+    a = _rand((M, K), 11).half()
+    w = _rand((N, K), 12, K ** -0.5).half()
+    bias, gamma = _rand((N,), 13), _rand((N,), 14) * 0.1 + 1
+    x0 = _rand((M, N), 15)
+    one = x0.clone()
+    C.gemm_h16(a, w, one, bias=bias, gamma=gamma, accumulate=True)
+    old = blocks.GEMM_MAX_OPERAND_ELEMENTS
+    blocks.GEMM_MAX_OPERAND_ELEMENTS = 1 << 20          # 1 024 rows of 768 per chunk (a multiple of 256)
+    try:
+        many = x0.clone()
+        blocks._gemm_rows(a, w, many, bias=bias, gamma=gamma, accumulate=True)
+    finally:
+        blocks.GEMM_MAX_OPERAND_ELEMENTS = old
+    ref = x0.double() + gamma.double() * (a.double() @ w.double().t() + bias.double())
+    assert float((many.double() - ref).norm() / ref.norm()) < 2e-6
+    assert float((many - one).abs().max()) < 1e-5 * float(one.abs().max())     # different tile kernels may serve the two forms
