@@ -232,3 +232,26 @@ def test_graph_capture_takes_the_estimated_shift_decision():
     finally:
         model.enable_graphs(False)
         precision.reset_guards(model)
+
+
+def test_graph_replay_on_the_x3_rung():
+    """The escalated forward as hipGraph segments: the plan (which blocks run on operand pairs) is taken from cached figures, so
+    capture involves no device read-back; the replayed outputs meet the fixture's gates like the eager ones."""
+    g = load_golden("full_s8_518_tlD")
+    m = g["meta"]
+    model = build_gpu_model(m["mode"], m["weight_seed"])
+    images = _images(g, m)
+    model.enable_graphs(True)
+    try:
+        model(images)                 # warm-ups + capture + first replay
+        pred = model(images)          # replay
+        torch.cuda.synchronize()
+        assert len(model.aggregator.escalation_report()["x3"]) == 71
+        ss = m["spatial_stride"]
+        for k in KEYS:
+            e = errors(pred[k][:, :, ::ss, ::ss], g[k])
+            assert e[1] < 1e-3, (k, e)
+        e = errors(torch.stack(pred["pose_enc"], 0), g["pose_enc"])
+        assert e[1] < 1e-3, e
+    finally:
+        model.enable_graphs(False)
