@@ -19,6 +19,12 @@ struct GemmParams {
     int accumulate;  // out_f32 += value
     int act;         // 0 none, 1 exact GELU, 2 ReLU
     int rows_in, rows_out, row_off;  // output row remap (rows_in == 0: identity)
+    // two-slice split-K of the 256 x 128 two-workgroups-per-CU kernel (gemm_bf16_duo.hip, round 5): per output tile two int32
+    // words {ticket, slab ready} (zero between launches: the last arriver resets them) and one fp32 slab of the tile's
+    // accumulators in register order; sk_err: one int32 that a workgroup sets when its bounded wait ran out.  nullptr: no split
+    int* sk_words;
+    float* sk_slab;
+    int* sk_err;
 };
 
 // Exact (erf) GELU, nn.GELU() of mlp.py:34.  erfc(|x|/sqrt2) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below
@@ -117,4 +123,7 @@ IGGT_DEVINL void gemm_epilogue_row4_nobias(const GemmParams& p, f32x4 v, int m, 
 // returns -100 when the parameter combination has no specialised big-tile kernel (caller falls back)
 int iggt_launch_gemm_t256(const GemmParams& p, int fmt, hipStream_t stream);
 // 256 x 128 tile, two workgroups per CU (gemm_bf16_duo.hip); same return convention
-int iggt_launch_gemm_duo(const GemmParams& p, int fmt, int rows, hipStream_t stream);
+int iggt_launch_gemm_duo(const GemmParams& p, int fmt, int rows, hipStream_t stream, bool splitk = false);
+// bytes of split-K workspace the duo kernel needs for (M, N) at `rows` rows per tile; layout: [err int32, pad to 64 B][2 int32 per
+// tile, padded to 256 B][fp32 slabs]
+long iggt_gemm_duo_splitk_bytes(int M, int N, int rows);

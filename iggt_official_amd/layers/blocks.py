@@ -88,6 +88,24 @@ class Workspace:
             self._bufs[name] = cur
         return cur[:n].view(*shape)
 
+    def get_zeroed(self, name, n, dtype, device):
+        """Flat buffer of n elements that is zero-filled when it is (re)allocated and never touched by this class again (the
+        split-K words of the GEMM dispatcher: the kernels leave them zero)."""
+        cur = self._bufs.get(name)
+        if cur is None or cur.numel() < n or cur.dtype != dtype or cur.device != device:
+            if cur is not None:
+                graphs.buffers_changed()
+            cur = torch.zeros(n, dtype=dtype, device=device)
+            self._bufs[name] = cur
+        return cur
+
+    def gemm_splitk(self, T, N, device):
+        """Workspace that lets _C.gemm_h16 split K over two workgroups per tile (include/iggt_hip.h iggt_gemm_*_ws): only where the
+        dispatcher can use it -- the two-workgroups-per-CU kernel's range of M (the per-rank shapes of a sharded run)."""
+        if not (1024 <= T < 8192):
+            return None
+        return self.get_zeroed("gemm_sk", _C.gemm_ws_bytes(T, N), torch.uint8, device)
+
     def get_padded(self, name, rows, cols, dtype, device, pad=ROW_PAD):
         """[rows, cols] view with a row stride of cols + pad elements (see ROW_PAD)."""
         return self.get(name, (rows, cols + pad), dtype, device)[:, :cols]
@@ -392,10 +410,11 @@ class Block(nn.Module):
         hid = ws.get("hid" + alt, (T, pk["w_fc1"].shape[0]), dt, dev)
 
         sat = precision.debug_saturation()
+        sk = ws.gemm_splitk(T, 3 * C, dev)          # (qkv has the most tiles of the GEMMs that split: sized for it)
         _C.layernorm(x2d, pk["n1w"], pk["n1b"], xn, self.norm1.eps)
         b_ = compensated_bias(ws, xn, pk["dw_qkv"], pk["b_qkv"])
         with profiling.region("gemm", ("qkv", T, 3 * C, C)):       # bench.py's secondary roofline leg: (name, M, N, K)
-            _C.gemm_h16(xn, pk["w_qkv"], qkv, bias=b_)
+            _C.gemm_h16(xn, pk["w_qkv"], qkv, bias=b_, ws=sk)
         if sat:
             precision.count_saturation("norm1", xn)
             precision.count_saturation("qkv", qkv)
@@ -499,7 +518,7 @@ class Block(nn.Module):
             precision.count_saturation("attn_out", ao)
         b_ = compensated_bias(ws, ao, pk["dw_proj"], pk["b_proj"])
         with profiling.region("gemm", ("proj", T, C, C)):
-            _C.gemm_h16(ao, pk["w_proj"], x2d, bias=b_, gamma=pk["g1"], accumulate=True)
+            _C.gemm_h16(ao, pk["w_proj"], x2d, bias=b_, gamma=pk["g1"], accumulate=True, ws=sk)
         _C.layernorm(x2d, pk["n2w"], pk["n2b"], xn, self.norm2.eps)
         b_ = compensated_bias(ws, xn, pk["dw_fc1"], pk["b_fc1"])
         with profiling.region("gemm", ("fc1", T, hid.shape[1], C)):
@@ -509,7 +528,7 @@ class Block(nn.Module):
             precision.count_saturation("mlp_hidden", hid)
         b_ = compensated_bias(ws, hid, pk["dw_fc2"], pk["b_fc2"])
         with profiling.region("gemm", ("fc2", T, C, hid.shape[1])):
-            _C.gemm_h16(hid, pk["w_fc2"], x2d, bias=b_, gamma=pk["g2"], accumulate=True)
+            _C.gemm_h16(hid, pk["w_fc2"], x2d, bias=b_, gamma=pk["g2"], accumulate=True, ws=sk)
         return x2d
 
     def _forward_x3(self, x2d, ws, pk, *, batch, tokens, rope_geom, kv_gather):
