@@ -102,7 +102,10 @@ class Workspace:
     def gemm_splitk(self, T, N, device):
         """Workspace that lets _C.gemm_h16 split K over two workgroups per tile (include/iggt_hip.h iggt_gemm_*_ws): only where the
         dispatcher can use it -- the two-workgroups-per-CU kernel's range of M (the per-rank shapes of a sharded run)."""
-        if not (1024 <= T < 8192):
+        # OFF by default -- built and measured in round 5 (profiles/r05_gemm_splitk_ab.txt, M = 5 496): qkv 61 -> 93 us, proj 27 -> 41,
+        # fc2 75.5 -> 80: at K = 1 024 the K loop is only half of a workgroup's time (pipeline fill + epilogue do not halve), at
+        # K = 4 096 two co-resident half-K workgroups gain less than the slab hand-over costs.  IGGT_GEMM_SPLITK=1 turns it on.
+        if not GEMM_SPLITK or not (1024 <= T < 8192):
             return None
         return self.get_zeroed("gemm_sk", _C.gemm_ws_bytes(T, N), torch.uint8, device)
 
@@ -126,6 +129,7 @@ def _h16_residual(w: torch.Tensor, dt: torch.dtype):
     return (w - w.to(dt).float()).to(dt).contiguous()
 
 
+GEMM_SPLITK = __import__("os").environ.get("IGGT_GEMM_SPLITK", "0") == "1"
 GEMM_MAX_OPERAND_ELEMENTS = 1 << 31   # csrc/gemm_bf16_t256.hip, gemm_bf16_duo.hip: M x lda and N x ldw below this
 
 
@@ -410,11 +414,11 @@ class Block(nn.Module):
         hid = ws.get("hid" + alt, (T, pk["w_fc1"].shape[0]), dt, dev)
 
         sat = precision.debug_saturation()
-        sk = ws.gemm_splitk(T, 3 * C, dev)          # (qkv has the most tiles of the GEMMs that split: sized for it)
+        gsk = ws.gemm_splitk(T, 3 * C, dev)         # None unless IGGT_GEMM_SPLITK=1 (measured slower: see Workspace.gemm_splitk)
         _C.layernorm(x2d, pk["n1w"], pk["n1b"], xn, self.norm1.eps)
         b_ = compensated_bias(ws, xn, pk["dw_qkv"], pk["b_qkv"])
         with profiling.region("gemm", ("qkv", T, 3 * C, C)):       # bench.py's secondary roofline leg: (name, M, N, K)
-            _C.gemm_h16(xn, pk["w_qkv"], qkv, bias=b_, ws=sk)
+            _C.gemm_h16(xn, pk["w_qkv"], qkv, bias=b_, ws=gsk)
         if sat:
             precision.count_saturation("norm1", xn)
             precision.count_saturation("qkv", qkv)
@@ -518,7 +522,7 @@ class Block(nn.Module):
             precision.count_saturation("attn_out", ao)
         b_ = compensated_bias(ws, ao, pk["dw_proj"], pk["b_proj"])
         with profiling.region("gemm", ("proj", T, C, C)):
-            _C.gemm_h16(ao, pk["w_proj"], x2d, bias=b_, gamma=pk["g1"], accumulate=True, ws=sk)
+            _C.gemm_h16(ao, pk["w_proj"], x2d, bias=b_, gamma=pk["g1"], accumulate=True, ws=gsk)
         _C.layernorm(x2d, pk["n2w"], pk["n2b"], xn, self.norm2.eps)
         b_ = compensated_bias(ws, xn, pk["dw_fc1"], pk["b_fc1"])
         with profiling.region("gemm", ("fc1", T, hid.shape[1], C)):
@@ -528,7 +532,7 @@ class Block(nn.Module):
             precision.count_saturation("mlp_hidden", hid)
         b_ = compensated_bias(ws, hid, pk["dw_fc2"], pk["b_fc2"])
         with profiling.region("gemm", ("fc2", T, C, hid.shape[1])):
-            _C.gemm_h16(hid, pk["w_fc2"], x2d, bias=b_, gamma=pk["g2"], accumulate=True, ws=sk)
+            _C.gemm_h16(hid, pk["w_fc2"], x2d, bias=b_, gamma=pk["g2"], accumulate=True, ws=gsk)
         return x2d
 
     def _forward_x3(self, x2d, ws, pk, *, batch, tokens, rope_geom, kv_gather):
