@@ -24,6 +24,10 @@ Prints ONE JSON line (rank 0) with value = total views / second, plus
   "output_check": relative l2 / max errors of the timed model's outputs against strided samples of the REFERENCE
               outputs (fixture produced by the reference modules on CPU fp32 at this very configuration) plus a
               checksum (mean / abs-sum per output) that tests/test_headline_gpu.py pins through the same fixture;
+  "precision_rung": which transformer blocks run on the x3 rung (fp16 hi + lo operand pairs, three MFMA passes per product;
+              iggt_official_amd/precision.py) on THIS checkpoint -- none on the BASELINE one -- and, when any do, the step time and the
+              output check of one extra forward with the rung switched off.  `--weights MODE` selects a heavy-tailed synthetic
+              checkpoint (with --views 8 the outputs are checked against the matching dose fixture);
   "cpu_baseline": the CPU restatement of the reference (oracle/restate.py, kind "port") timed on this
               box's host cores on a bounded sample (4 views @ 518x518 = BASELINE.json configs[0]'s size), plus a
               32-view figure extrapolated from a row-sampled global attention (flagged as such), rank 0 / N=1 only.
