@@ -229,11 +229,16 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkParams p) {
     const int pos = (j < 4) ? py : px;
     const int f0 = (j & 1) * 8;
     float y[8];
+    // the 8 cosines / sines of this slice are contiguous in the table: two 16-byte loads each (as 16 scalar loads the table
+    // reads were 16 of the kernel's 18 vector-memory instructions per token)
+    const f32x4* ct = reinterpret_cast<const f32x4*>(p.cos_t + pos * 16 + f0);
+    const f32x4* st = reinterpret_cast<const f32x4*>(p.sin_t + pos * 16 + f0);
+    const f32x4 c0 = ct[0], c1 = ct[1], s0 = st[0], s1 = st[1];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float partner = __shfl_xor(x[e], 2, 64);
         const float rot = (j & 2) ? partner : -partner;
-        const float cs = p.cos_t[pos * 16 + f0 + e], sn = p.sin_t[pos * 16 + f0 + e];
+        const float cs = e < 4 ? c0[e & 3] : c1[e & 3], sn = e < 4 ? s0[e & 3] : s1[e & 3];
         y[e] = x[e] * cs + rot * sn;
     }
     if (which == 0 && p.q_scale != 1.0f) {
@@ -653,6 +658,7 @@ static int qknorm_rope_h16(int fmt, const void* qkv, long ld_in, void* q_out, lo
     if (T <= 0 || P <= 0) return -1;
     if (!(q_scale > 0.f)) return -4;
     if ((ld_in % 8) || (ldq % 8) || (ldk % 8) || (v_out && (ldv % 8))) return -2;
+    if (((uintptr_t)cos_t | (uintptr_t)sin_t) % 16) return -2;   // the tables are read as 16-byte vectors
     QkParams p;
     p.qkv = (const bf16_t*)qkv; p.ld_in = ld_in;
     p.q_out = (bf16_t*)q_out; p.ldq = ldq; p.k_out = (bf16_t*)k_out; p.ldk = ldk;

@@ -339,11 +339,14 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const QkvSplitParams p) 
             }
             const int pos = (j < 4) ? py : px;
             const int f0 = (j & 1) * 8;
+            const f32x4* ct = reinterpret_cast<const f32x4*>(p.cos_t + pos * 16 + f0);
+            const f32x4* st = reinterpret_cast<const f32x4*>(p.sin_t + pos * 16 + f0);
+            const f32x4 c0 = ct[0], c1 = ct[1], s0 = st[0], s1 = st[1];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float partner = __shfl_xor(x[e], 2, 64);
                 const float rot = (j & 2) ? partner : -partner;
-                const float cs = p.cos_t[pos * 16 + f0 + e], sn = p.sin_t[pos * 16 + f0 + e];
+                const float cs = e < 4 ? c0[e & 3] : c1[e & 3], sn = e < 4 ? s0[e & 3] : s1[e & 3];
                 y[e] = x[e] * cs + rot * sn;
             }
         } else {
@@ -422,6 +425,7 @@ extern "C" int iggt_qkv_split_f16(const float* qkv, long ld_in, void* q_out, lon
     if ((ld_in % 4) || (ldq % 8) || (ldk % 8) || (ldv % 8) || (q_lo % 8) || (k_lo % 8) || (v_lo % 8)) return -2;
     if ((qw == nullptr) != (kw == nullptr) || (qw != nullptr && (qb == nullptr || kb == nullptr))) return -3;
     if ((cos_t == nullptr) != (sin_t == nullptr) || (cos_t != nullptr && (P <= 0 || gw <= 0))) return -3;
+    if (((uintptr_t)cos_t | (uintptr_t)sin_t) % 16) return -2;   // the tables are read as 16-byte vectors
     QkvSplitParams p;
     p.qkv = qkv; p.ld_in = ld_in;
     p.q_out = (bf16_t*)q_out; p.ldq = ldq; p.q_lo = q_lo;

@@ -182,7 +182,7 @@ int iggt_layernorm_f32(const float* x0, long ld0, const float* x1, long ld1, con
                        void* stream);
 
 /* Per-head LayerNorm(64) on q,k + 2-D RoPE (+ optional v copy) on a 16-bit [T][3*1024] qkv matrix.
- * cos_t/sin_t: fp32 [max_pos+1][16].  heads_per_group in {1,2,4,8} writes k / v in head-group layout -- head h of
+ * cos_t/sin_t: fp32 [max_pos+1][16], 16-byte aligned.  heads_per_group in {1,2,4,8} writes k / v in head-group layout -- head h of
  * token t at out + (h / hpg) * group_stride + t * ld + (h % hpg) * 64 -- so that the multi-GPU K/V all-gather can be
  * pipelined over head groups (iggt_official_amd/dist.py); 0 or 16: flat rows.  q_scale (> 0; 1 = none) is folded into the q
  * output (the softmax scale * log2 e for iggt_flash_attn_static_*); qkmax (NULL, or float[32 + 32 * 4096]: 32 results + scratch
