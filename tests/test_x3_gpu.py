@@ -271,3 +271,44 @@ def test_gemm_row_chunks_equal_one_launch(C):
     ref = x0.double() + gamma.double() * (a.double() @ w.double().t() + bias.double())
     assert float((many.double() - ref).norm() / ref.norm()) < 2e-6
     assert float((many - one).abs().max()) < 1e-5 * float(one.abs().max())     # different tile kernels may serve the two forms
+
+
+@pytest.mark.parametrize("case", ["tiny_s2_56_stress", "tiny_s3_84x56_stress"])
+def test_whole_model_on_the_rung_at_small_shapes(case):
+    """Every block forced onto the rung (IGGT_ESCALATE=all) on the bounded-uniform checkpoint at the smallest shapes -- 21 / 29
+    tokens per view: the GEMMs fall to the 128^2 kernel with K = 3 072 / 12 288, the pair attention runs ragged tiles, the part
+    head consumes the tokens -- and as a batch of two scenes (B = 2).  The aggregated tokens must sit an order of magnitude closer
+    to the reference than on single operands; every output inside its usual gate."""
+    from conftest import load_golden
+    from helpers import build_gpu_model, errors
+    from iggt_official_amd import precision
+    from oracle import weights
+
+    g = load_golden(case)
+    m = g["meta"]
+    model = build_gpu_model(m["mode"], m["weight_seed"])
+    images = weights.make_images(m["S"], m["H"], m["W"], seed=m["image_seed"], device="cuda")
+    cap = {}
+    hook = model.aggregator.register_forward_hook(lambda mod, i, o: cap.__setitem__("tokens", o[0]))
+    res = {}
+    try:
+        for mode in ("off", "all"):
+            precision.set_escalation(mode)
+            pred = model(images)
+            torch.cuda.synchronize()
+            assert len(model.aggregator.escalation_report()["x3"]) == (72 if mode == "all" else 0)
+            res[mode] = {f"tokens_{li}": errors(cap["tokens"][li], g[f"tokens_{li}"])[1] for li in (4, 11, 17, 23)}
+            for k in ("depth", "world_points", "part_feat"):
+                if k in g:
+                    res[mode][k] = errors(pred[k], g[k])[1]
+            res[mode]["pose_enc"] = errors(torch.stack(pred["pose_enc"], 0), g["pose_enc"])[1]
+        two = model(torch.stack([images, images.flip(0)], 0))        # B = 2 scenes on the rung
+        torch.cuda.synchronize()
+        assert two["depth"].shape[0] == 2 and errors(two["depth"][:1], pred["depth"])[1] < 1e-6
+    finally:
+        precision.set_escalation("auto")
+        hook.remove()
+    report(f"x3/whole_model/{case}", res)
+    for k, v in res["all"].items():
+        assert v < 1e-3, (k, v)
+    assert res["all"]["tokens_23"] < res["off"]["tokens_23"] / 10, res
