@@ -322,6 +322,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
     // ---- epilogue: 128 pixels per pass through LDS, then whole contiguous channel runs per pixel -----------------------
     wait_vm<0>();
     __syncthreads();
+#ifdef IGGT_CONV_NO_EPILOGUE   // ablation build (probes/build_alt.py conv_noepi): what the epilogue costs; results are garbage
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+        if (sum == 1.2345e-30f) p.y[0] = sum;
+        return;
+    }
+#endif
     float* stile = reinterpret_cast<float*>(smem);
     constexpr int C4 = BN / 4;
     constexpr int WM_PER_PASS = WAVES_M / 2;

@@ -14,6 +14,8 @@ VARIANTS = {
     "attn_nopin": {"attention_v3.hip": ["-DIGGT_ATTN_NO_PIN"]},
     "attn_nopin_noslp": {"attention_v3.hip": ["-DIGGT_ATTN_NO_PIN", "-fno-slp-vectorize"]},
     "hdb_stats": {"hdbscan.hip": ["-DIGGT_HDB_STATS"]},
+    # round 5: the halo convolution without its epilogue (ablation: upper bound of what a cheaper epilogue could save)
+    "conv_noepi": {"conv3x3_halo.hip": ["-DIGGT_CONV_NO_EPILOGUE"]},
     # estimated-shift instantiation of the static attention kernel (round 4; timed by probes/attn_est_ab.py)
     "est_default_sched": {"attention_v3_est.hip": []},
     "est_nodelta_maxilp": {"attention_v3_est.hip": ["-DIGGT_EST_NODELTA", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]},
