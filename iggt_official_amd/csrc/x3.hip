@@ -20,6 +20,8 @@
 // (LayerNorm and the patch-embed im2row write [hi | lo | hi] through a new output kind of their existing entry points.)
 // Same LDS images, swapped-QK^T / in-register-P scheme and DMA staging as attention_v3.hip (128-row workgroups, 64-key tiles,
 // online max): this is the precision path, scheduled by the compiler; per 32 x 64 score block 48 MFMAs instead of 16.
+#include <stdlib.h>
+
 #include "attention_common.h"
 #include "../../include/iggt_hip.h"
 
@@ -54,6 +56,10 @@ IGGT_DEVINL HiLo split_pack(float a, float b) {
     return r;
 }
 
+// PSPLIT = false (IGGT_X3_P_SINGLE=1, measurement only): the softmax numerators stay single fp16 -- O in two passes, 40 instead of
+// 48 MFMAs per score block.  The numerators are the smallest of the rounding sites (profiles/r05_precision_groups.txt: 5.8e-4 alone
+// in the CPU simulation); DESIGN.md section 2 has what the dose fixtures measure with it.  The shipped rung splits them.
+template <bool PSPLIT>
 __global__ __launch_bounds__(256, 2) void flash_attn_x3_kernel(const X3Params p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * X3_TILE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_x3_kernel(const X3Params p)
                     const bf16x8 vl_ = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
                     const bf16x8 vh_ = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
                     o[dh] = mfma32h<FMT_F16>(vl_, ph[kvh][cc], o[dh]);
-                    o[dh] = mfma32h<FMT_F16>(vh_, pl[kvh][cc], o[dh]);
+                    if constexpr (PSPLIT) o[dh] = mfma32h<FMT_F16>(vh_, pl[kvh][cc], o[dh]);
                     o[dh] = mfma32h<FMT_F16>(vh_, ph[kvh][cc], o[dh]);
                 }
         __syncthreads();   // everyone done with buffer t & 1; the DMA of tile t + 1 has landed
@@ -411,7 +417,13 @@ extern "C" int iggt_flash_attn_x3_f16_d64(const void* q, const void* q_lo, const
     p.qtiles = (Nq + 127) / 128;
     const long nwg = (long)B * H * p.qtiles;
     if (nwg > 0x7fffffffL) return -1;
-    hipLaunchKernelGGL(flash_attn_x3_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+    static int p_single = -1;
+    if (p_single < 0) {
+        const char* e = getenv("IGGT_X3_P_SINGLE");
+        p_single = (e && e[0] == '1') ? 1 : 0;
+    }
+    if (p_single) hipLaunchKernelGGL(flash_attn_x3_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(flash_attn_x3_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
     return 0;
 }
