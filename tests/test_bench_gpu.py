@@ -38,6 +38,23 @@ def test_bench_single_gpu_line():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["output_check"]["ok"]
+    # round 5: the BASELINE checkpoint pays nothing for the precision rung
+    assert d["precision_rung"]["escalated"] == 0 and d["precision_rung"]["blocks"] == 72 and d["precision_rung"]["policy"] == "auto"
+
+
+def test_bench_on_a_heavy_tailed_checkpoint_reports_the_rung():
+    """`--weights` + `precision_rung`: on the sigma 1 / 0.5 dose 71 of 72 blocks escalate, the timed (escalated) model passes the
+    dose fixture's check, the extra single-operand forward does not, and both step times are in the line."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--views", "8", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline", "--weights", "trained_like(qk=1,norm=0.5)"], capture_output=True, text=True, cwd=ROOT,
+                         timeout=600, env=dict(os.environ, IGGT_BENCH_WORSTCASE="0", IGGT_BENCH_BF16_LEG="0"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    rung = d["precision_rung"]
+    assert rung["escalated"] == 71 and 0 < rung["ill_conditioned_by_own_figures"] < 71
+    assert d["output_check"]["ok"] and d["output_check"]["fixture"].endswith("full_s8_518_tlD.pt")
+    assert rung["single_fp16_output_check"]["max_l2"] > d["output_check"]["max_l2"]
+    assert rung["ms_per_step"] > rung["ms_per_step_single_fp16_operands"] > 0
 
 
 def test_bench_two_rank_control_flow():
