@@ -141,3 +141,43 @@ def test_query_points_argument_forms():
     for bad, b in ((torch.zeros(5, 3), 1), (torch.zeros(2, 5, 2), 1), (torch.zeros(5), 1)):
         with pytest.raises(ValueError):
             IGGT._query(bad, b)
+
+
+def _worker_mixed_forms(rank, world, port, ret):
+    """Round 5: whether a rank's call site runs the overlapped form (all_gather_kv_begin ... finish) or the gather-first form of
+    the estimated shift (all_gather_kv with stats) is that RANK'S OWN decision (layers/blocks.py use_est).  Ranks that disagree
+    must still be issuing the same collectives in the same order: here rank 0 takes one form and rank 1 the other, block after
+    block, alternating -- both must end with identical gathered buffers, and the pair-operand message ([T_local, 4C]) of the x3
+    rung travels through the same call."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from iggt_official_amd.dist import ViewShard
+
+        torch.manual_seed(1)
+        S, P, C = 4, 7, 128
+        shard = ViewShard()
+        v0, v1 = shard.local_views(S)
+        for blk in range(6):
+            kv = torch.randn(S * P, 2 * C, generator=torch.Generator().manual_seed(100 + blk)).half()
+            stats_all = torch.stack([torch.arange(32, dtype=torch.float32) * (blk + 1) + 1000.0 * r for r in range(world)])
+            mine, st = kv[v0 * P:v1 * P].contiguous(), stats_all[rank].clone()
+            if (blk + rank) % 2 == 0:                 # this rank: overlapped form
+                out, sout, fin = shard.all_gather_kv_begin(mine, st)
+                fin()
+            else:                                     # this rank: gather-first (estimated-shift) form
+                out, sout = shard.all_gather_kv(mine, st)
+            assert torch.equal(out, kv) and torch.equal(sout, stats_all), (rank, blk)
+            pairs = torch.randn(S * P, 4 * C, generator=torch.Generator().manual_seed(200 + blk)).half()   # x3: [k_hi|v_hi|k_lo|v_lo]
+            assert torch.equal(shard.all_gather_kv(pairs[v0 * P:v1 * P].contiguous()), pairs)
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_may_disagree_on_the_attention_form():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_mixed_forms, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
