@@ -28,6 +28,10 @@ Prints ONE JSON line (rank 0) with value = total views / second, plus
               iggt_official_amd/precision.py) on THIS checkpoint -- none on the BASELINE one -- and, when any do, the step time and the
               output check of one extra forward with the rung switched off.  `--weights MODE` selects a heavy-tailed synthetic
               checkpoint (with --views 8 the outputs are checked against the matching dose fixture);
+  "full_model": the WHOLE model incl. the instance-feature branch (`part_feat`) at the same view count @ 532 x 532 (where the
+              reference's part head is defined): views/s, the global-attention roofline at that size, per-kernel-family entries
+              for the part branch (its convolutions, the two window-attention stages, the token cross-attention) and the
+              output check -- part_feat included -- against the reference fixture of that configuration;
   "cpu_baseline": the CPU restatement of the reference (oracle/restate.py, kind "port") timed on this
               box's host cores on a bounded sample (4 views @ 518x518 = BASELINE.json configs[0]'s size), plus a
               32-view figure extrapolated from a row-sampled global attention (flagged as such), rank 0 / N=1 only.
@@ -61,7 +65,9 @@ try:
         PMC_TRAFFIC = json.load(_f)
 except Exception:  # noqa: BLE001
     PMC_TRAFFIC = {}
-FIXTURES = {(32, 518): ("full_s32_518_stress", 8), (8, 518): ("full_s8_518_stress", 7)}   # (views, size) -> (fixture, image seed)
+FIXTURES = {(32, 518): ("full_s32_518_stress", 8), (8, 518): ("full_s8_518_stress", 7),    # (views, size) -> (fixture, image seed)
+            (32, 532): ("full_s32_532_stress", 11), (8, 532): ("full_s8_532_stress", 10)}    # 532^2: the WHOLE model incl. part_feat
+FULL_MODEL_SIZE = 532     # nearest size above 518 on which the reference's part head is defined (H, W in 28 N)
 # --weights <mode>: the heavy-tailed dose fixtures (8 views @ 518^2; iggt_official_amd/synthetic.py "trained_like", oracle/make_golden.py)
 DOSE_FIXTURES = {"trained_like(qk=0.5,norm=0.5)": "full_s8_518_tlA", "trained_like(qk=0.75,norm=0.5)": "full_s8_518_tlB",
                  "trained_like": "full_s8_518_tlC", "trained_like(qk=1,norm=0.5)": "full_s8_518_tlD",
@@ -157,8 +163,8 @@ def output_check(pred, S, H, v0, v1, dev, mode="stress"):
     g = torch.load(path, map_location="cpu", weights_only=False)
     ss = g["meta"]["spatial_stride"]
     out = {"fixture": "tests/golden/" + fx[0] + ".pt", "errors": {}, "checksum": {}}
-    for k in ("depth", "depth_conf", "world_points", "world_points_conf"):
-        got = pred[k][:, :, ::ss, ::ss].double().cpu()
+    for k in ("depth", "depth_conf", "world_points", "world_points_conf") + (("part_feat",) if ("part_feat" in g and "part_feat" in pred) else ()):
+        got = (pred[k][:, :, :, ::ss, ::ss] if k == "part_feat" else pred[k][:, :, ::ss, ::ss]).double().cpu()
         ref = g[k][:, v0:v1].double()
         d = got - ref
         out["errors"][k] = {"l2": float(d.norm() / ref.norm()), "max": float(d.abs().max() / ref.abs().max())}
@@ -184,7 +190,7 @@ def _secondary_rooflines(g_recs, c_recs):
     ALGORITHMIC rate is what is reported; `mfma_equivalent` is 3x that."""
     out = []
     by = {}
-    for ms, (name, M, N, K) in g_recs:
+    for ms, (name, M, N, K), _tag in g_recs:
         d = by.setdefault(name, [0.0, 0.0, 0, (M, N, K)])
         d[0] += ms
         d[1] += 2.0 * M * N * K
@@ -277,6 +283,100 @@ def _worstcase_attention(S, P, dev, dt):
             "timing_note": "HIP events, mean of 10 launches after 3 warm-up launches of a cold call site"}
 
 
+def _full_model_leg(model, dev, S, mode, steps):
+    """`full_model`: the WHOLE model -- trunk, camera / depth / point heads AND the instance-feature branch (`part_feat`:
+    SamProjector + PartHead with its token cross-attention and the two window-attention stages; reference vggt.py:204-218) --
+    at S views @ 532 x 532, the nearest size above BASELINE's 518 on which the reference's part head is defined (H, W in 28 N).
+    The headline configuration cannot carry it: at 518^2 the reference raises inside the part head.  Same
+    model object as the headline (same weights, same packs), synthetic images of the reference fixture of this size; timed like the
+    headline (synchronise, `steps` forwards, synchronise), outputs incl. part_feat checked against the fixture the REFERENCE
+    modules produced at this very configuration, then ONE extra eager forward with HIP events around every launch of the part
+    branch's kernel families (the two DPT heads in line for it)."""
+    from iggt_official_amd import _C, precision, profiling, synthetic
+    from iggt_official_amd.models import vggt as _mv
+
+    H = FULL_MODEL_SIZE
+    P, C = 5 + (H // 14) ** 2, 1024
+    fx = FIXTURES.get((S, H))
+    images = synthetic.make_images(S, H, H, seed=fx[1] if fx else 1234, device=dev)
+    torch.cuda.reset_peak_memory_stats(dev)
+    for _ in range(2):                # warm-up: workspaces of the larger grid, the part branch's weight packs
+        model(images)
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = model(images)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    assert "part_feat" in out and all(torch.isfinite(v).all() for v in out.values() if torch.is_tensor(v))
+    check = output_check(out, S, H, 0, S, dev, mode)
+    names = ("global_attn", "conv", "window_attn", "cross_attn", "part_branch")
+    orig = _mv._HEAD_STREAMS
+    try:
+        _mv._HEAD_STREAMS = "0"
+        for nm in names:
+            profiling.enable(nm)
+        model(images)
+        torch.cuda.synchronize()
+        recs = {nm: profiling.summarize(profiling.disable(nm) or []) for nm in names}
+    finally:
+        _mv._HEAD_STREAMS = orig
+        for nm in names:
+            profiling.disable(nm)
+
+    def fam(rs, peak, unit_flops=True):
+        t = sum(r[0] for r in rs)
+        fl = sum(r[1][1] if isinstance(r[1][0], str) else r[1][0] for r in rs)
+        return {"launches": len(rs), "ms_per_forward": t, "algorithmic_tflop_per_forward": fl / 1e12,
+                "achieved": fl / max(t, 1e-9) / 1e9, "peak": peak, "unit": "TFLOP/s", "frac": fl / max(t, 1e-9) / 1e9 / peak}
+
+    ga = recs["global_attn"]
+    ga_ms = sum(r[0] for r in ga) / max(len(ga), 1)
+    ga_fl = 4.0 * (S * P) ** 2 * C
+    part_conv = [r for r in recs["conv"] if r[2] == "part"]
+    dpt_conv = [r for r in recs["conv"] if r[2] != "part"]
+    sec = []
+    if part_conv:
+        e = fam(part_conv, MFMA_BF16_PEAK_TFLOPS)
+        passes = sum(r[1][0] * r[1][1] for r in part_conv) / max(sum(r[1][0] for r in part_conv), 1.0)
+        e.update(kernel="conv_igemm_kernel / conv3x3_halo_kernel, part branch (SamProjector `Projects` stacks with folded BatchNorm, "
+                        "PartHead fusion blocks, SwinSA / SwinCA convolutions, the part head's Linear layers as 1x1 convolutions)",
+                 bound="mfma", mfma_passes_per_product=passes, mfma_equivalent_tflops=e["achieved"] * passes)
+        sec.append(e)
+    for kind in sorted({r[1][0] for r in recs["window_attn"]}):
+        rs = [r for r in recs["window_attn"] if r[1][0] == kind]
+        e = fam(rs, 157.3)
+        e.update(kernel=f"window_attn_kernel ({kind}; fp32 on the vector ALU: one wave per (window, head), lane = query)",
+                 bound="valu-fp32", peak_note="fp32 vector / matrix peak of the guide (157.3 TFLOP/s); the stage is < 0.2 TFLOP")
+        sec.append(e)
+    if recs["cross_attn"]:
+        e = fam(recs["cross_attn"], 157.3)
+        e.update(kernel="attn_f32_kernel<32> (PartHead.cross_attention_2: g^2 part tokens x g^2 point-feature tokens, 8 heads, "
+                        "exact fp32 MFMA v_mfma_f32_32x32x2_f32)", bound="mfma-fp32")
+        sec.append(e)
+    if dpt_conv:
+        e = fam(dpt_conv, MFMA_BF16_PEAK_TFLOPS)
+        e.update(kernel="conv3x3_halo_kernel / conv_igemm_kernel, the two DPT heads at this size", bound="mfma")
+        sec.append(e)
+    pb = sum(r[0] for r in recs["part_branch"])
+    return {
+        "workload": f"{S} views @ {H}x{H}, IGGT forward incl. part_feat (DINOv2 + 24x(frame,global) + camera / depth / point heads + "
+                    "SamProjector + PartHead), same synthetic checkpoint as the headline",
+        "value": S / (ms * 1e-3), "unit": "views/s", "ms_per_step": ms, "steps": steps, "warmup": 2, "views": S, "image_size": H,
+        "tokens_per_view": P, "peak_memory_gib": torch.cuda.max_memory_allocated(dev) / 2.0 ** 30,
+        "part_branch_ms_per_forward": pb,
+        "part_branch_note": "HIP events around part_adaptor + part_head in the per-kernel forward (heads in line); in the timed "
+                            "steps the depth head runs beside the point head on a second stream",
+        "roofline": {"bound": "mfma", "kernel": _C.attn_kernel_label(1, 16, S * P, S * P, precision.operand_name(),
+                                                                     static_bound=precision.static_softmax(), with_part_ws=True)
+                     + " (global attention)", "achieved": ga_fl / max(ga_ms, 1e-9) / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": ga_fl / max(ga_ms, 1e-9) / 1e9 / MFMA_BF16_PEAK_TFLOPS, "ms_per_launch": ga_ms,
+                     "launches_timed": len(ga), "flops_per_launch": ga_fl},
+        "roofline_secondary": sec,
+        "output_check": check,
+    }
+
+
 def _self_launch(n):
     """Re-execute this script as n ranks of one node: python -m torch.distributed.run --nnodes=1 --nproc-per-node n
     --master-addr 127.0.0.1 --master-port <free port> bench.py <the same arguments>.  stdout / stderr pass through."""
@@ -306,6 +406,8 @@ def main():
     ap.add_argument("--views", type=int, default=32)
     ap.add_argument("--size", type=int, default=518)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-model", action="store_true",
+                    help="skip the `full_model` leg (the whole model incl. part_feat at 532^2, a few extra forwards behind the timed region)")
     ap.add_argument("--cpu-sample-views", type=int, default=4)
     ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
                     help="replay the forward as hipGraph segments (auto: when N > 1, where the per-rank forward is host-bound)")
@@ -450,6 +552,7 @@ def main():
             "policy": precision.escalation()}
     if rung["escalated"]:
         was_graphs = model._graphs_on
+        prev_policy = precision.escalation_policy()      # "auto", or IGGT_ESCALATE=all (the maximum-parity mode): restored below
         try:
             model.enable_graphs(False)
             precision.set_escalation("off")
@@ -461,7 +564,7 @@ def main():
             rung["ms_per_step_single_fp16_operands"] = (time.perf_counter() - t1) * 1e3
             rung["single_fp16_output_check"] = None if (args.random_init or emu) else output_check(step(), S, H, v0, v1, dev, args.weights)
         finally:
-            precision.set_escalation("auto")
+            precision.set_escalation(prev_policy)
             step()            # re-pack on the rung (the legs below time the shipping configuration)
             fence()
             model.enable_graphs(was_graphs)
@@ -515,6 +618,15 @@ def main():
         dt = float(t.item())
     assert all(torch.isfinite(v).all() for v in out.values() if torch.is_tensor(v))
     check = None if (args.random_init or emu) else output_check(out, S, H, v0, v1, dev, args.weights)
+    peak_mem = torch.cuda.max_memory_allocated(dev) / 2.0 ** 30
+    full_model = None
+    if world == 1 and not emu and not force_coll and not args.no_full_model and not args.random_init and H == 518:
+        try:
+            if graphs:
+                model.enable_graphs(False)
+            full_model = _full_model_leg(model, dev, S, args.weights, max(1, min(args.steps, 5)))
+        except Exception as ex:  # noqa: BLE001  (never lose the main line to a side measurement)
+            full_model = {"error": repr(ex)[:300]}
     if world > 1 and check is not None:   # worst rank decides
         t = torch.tensor([check["max_l2"]], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -554,7 +666,7 @@ def main():
             "dtype": precision.operand_name(),
             "data": data,
             "graphs": bool(graphs),
-            "peak_memory_gib": torch.cuda.max_memory_allocated(dev) / 2.0 ** 30,
+            "peak_memory_gib": peak_mem,
             **({"graphs_note": graph_note} if graph_note else {}),
             **({"emulated_rank": {"world": emu, "rank": shard.rank, "views_of_this_rank": v1 - v0,
                                   "job_views_per_s_if_transport_were_free": S * args.steps / dt,
@@ -613,6 +725,8 @@ def main():
             line["roofline_worstcase"] = worst
         if check is not None:
             line["output_check"] = check
+        if full_model is not None:
+            line["full_model"] = full_model
         if world == 1 and not emu and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.cpu_sample_views, H)

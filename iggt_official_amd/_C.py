@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("IGGT_HIP_LIB") or os.path.join(os.path.dirname(os.pa
                                                            "libiggt_hip.so")
 _lib = None
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _c_void_p, _c_int, _c_long, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -27,13 +27,6 @@ _SIGNATURES = {
     "iggt_gemm_f16": [_c_void_p, _c_long, _c_void_p, _c_long, _c_int, _c_int, _c_int,
                       _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int,
                       _c_int, _c_int, _c_int, _c_void_p],
-    "iggt_gemm_bf16_ws": [_c_void_p, _c_long, _c_void_p, _c_long, _c_int, _c_int, _c_int,
-                          _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int,
-                          _c_int, _c_int, _c_int, _c_void_p, _c_long, _c_void_p],
-    "iggt_gemm_f16_ws": [_c_void_p, _c_long, _c_void_p, _c_long, _c_int, _c_int, _c_int,
-                         _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int,
-                         _c_int, _c_int, _c_int, _c_void_p, _c_long, _c_void_p],
-    "iggt_gemm_ws_bytes": [_c_int, _c_int],
     "iggt_flash_attn_bf16_d64": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                                  _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long,
                                  _c_float, _c_int, _c_void_p],
@@ -211,18 +204,11 @@ def _h16(*ts):
     return "f16" if dt == torch.float16 else "bf16"
 
 
-def gemm_ws_bytes(M, N):
-    """Bytes of split-K workspace gemm_h16(..., ws=...) can use for an (M, N) problem."""
-    return int(load().iggt_gemm_ws_bytes(int(M), int(N)))
-
-
 def gemm_h16(a, w, out, *, bias=None, gamma=None, add_table=None, accumulate=False, act=0,
-              rows_in=0, rows_out=0, row_off=0, M=None, ws=None):
+              rows_in=0, rows_out=0, row_off=0, M=None):
     """out[row(m)] (=|+=) act(a @ w.T + bias) * gamma (+ add_table).  a [M,K] and w [N,K] bf16 or fp16 (row
-    stride ok), out fp32 or the operands' 16-bit type, 2-D with unit column stride.
-    ws: optional uint8 workspace (gemm_ws_bytes; zero-filled when it was allocated, one per stream): lets the dispatcher split K
-    over two workgroups per output tile on small grids (include/iggt_hip.h iggt_gemm_*_ws)."""
-    _dev(a, w, out, bias, gamma, add_table, ws)
+    stride ok), out fp32 or the operands' 16-bit type, 2-D with unit column stride."""
+    _dev(a, w, out, bias, gamma, add_table)
     sfx = _h16(a, w) if out.dtype == torch.float32 else _h16(a, w, out)
     assert a.stride(-1) == 1 and w.stride(-1) == 1 and out.stride(-1) == 1
     M = a.shape[0] if M is None else M
@@ -230,15 +216,6 @@ def gemm_h16(a, w, out, *, bias=None, gamma=None, add_table=None, accumulate=Fal
     assert a.shape[1] == K
     for t in (bias, gamma, add_table):
         assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
-    if ws is not None:
-        assert ws.dtype == torch.uint8 and ws.is_contiguous()
-        fn = getattr(load(), "iggt_gemm_" + sfx + "_ws")
-        rc = fn(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), M, N, K,
-                _ptr(bias), _ptr(gamma), _ptr(add_table), out.data_ptr(), out.stride(0),
-                int(out.dtype == torch.float32), int(accumulate), act, rows_in, rows_out, row_off, ws.data_ptr(), ws.numel(),
-                _stream())
-        _check(rc, "iggt_gemm_" + sfx + "_ws")
-        return out
     fn = getattr(load(), "iggt_gemm_" + sfx)
     rc = fn(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), M, N, K,
             _ptr(bias), _ptr(gamma), _ptr(add_table), out.data_ptr(), out.stride(0),

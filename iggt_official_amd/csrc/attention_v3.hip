@@ -492,7 +492,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
             NMT = (int)((long)(ks + 1) * NMT_all / p.ksplit);
         }
     }
-    // the tile loop, in two copies for the estimated-shift kernel: with and without the second block's shift correction
+    // the tile loop, in two copies for the estimated-shift kernel: with and without the second block's shift correction (chosen
+    // per workgroup, below)
     auto tile_loop = [&](auto use_delta) {
         dma(mt0, mt0 & 1);
         __syncthreads();  // vmcnt(0) + barrier: first macro tile resident
@@ -529,9 +530,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         }
     };
     if constexpr (EST && QB == 2 && !EST_NODELTA) {
-        // per wave: only if some lane's two rows differ by more than IGGT_EST_DELTA_MAX bits (the pre-pass dealt the rows in
-        // shift order, so neighbours rarely do)
-        if (__any(fabsf(est_delta) > IGGT_EST_DELTA_MAX)) tile_loop(std::true_type{});
+        // per WORKGROUP: the correction only if some lane's two rows differ by more than IGGT_EST_DELTA_MAX bits (the pre-pass
+        // dealt the tile's 256 rows in shift order, so neighbours rarely do).  Each copy of the tile loop has its own
+        // __syncthreads(): the choice must be the same for all four waves, or waves of one workgroup would wait at DIFFERENT
+        // barrier instructions -- which the hardware's counted barriers tolerate and the HIP execution model does not define
+        // (round 4 / 5 chose per wave: ADVICE r4, r5).  __syncthreads_or is itself a barrier every wave reaches.
+        if (__syncthreads_or(fabsf(est_delta) > IGGT_EST_DELTA_MAX)) tile_loop(std::true_type{});
         else tile_loop(std::false_type{});
     } else {
         tile_loop(std::false_type{});

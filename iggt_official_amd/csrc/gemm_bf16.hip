@@ -332,7 +332,7 @@ static int force_small_tile() {
 
 static int gemm_h16(int fmt, const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
                     const float* gamma, const float* add_table, void* out, long ldo, int out_is_f32, int accumulate,
-                    int act, int rows_in, int rows_out, int row_off, void* stream, void* ws = nullptr, long ws_bytes = 0) {
+                    int act, int rows_in, int rows_out, int row_off, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0) return -1;
     if ((lda % 8) != 0 || (ldw % 8) != 0) return -2;  // 16-B aligned operand rows
     if (accumulate && !out_is_f32) return -3;
@@ -349,7 +349,6 @@ static int gemm_h16(int fmt, const void* A, long lda, const void* W, long ldw, i
     p.ldo = ldo;
     p.accumulate = accumulate; p.act = act;
     p.rows_in = rows_in; p.rows_out = rows_out; p.row_off = row_off;
-    p.sk_words = nullptr; p.sk_slab = nullptr; p.sk_err = nullptr;
     // large problems: 256x256 LDS-DMA kernel (gemm_bf16_t256.hip); small / ragged-N ones: this 128x128 kernel
     // Exception: grids of < 128 big tiles (e.g. N = 1024 with a few thousand rows: the per-rank proj / fc2 GEMMs of an
     // 8-GPU run) leave most CUs idle -- the 128^2 kernel's 4x finer grid wins there (measured 108 vs 131 us).
@@ -380,32 +379,9 @@ static int gemm_h16(int fmt, const void* A, long lda, const void* W, long ldw, i
     const int rows = (duo192 && cost192 < cost256) ? 192 : 256;
     // (An earlier remedy for the qkv shape -- 21 x 24 full 256-row tiles here + the last 120 rows on the 128^2 kernel, 61.7 us --
     // is gone: wherever it saved a round, 192-row tiles save it too and win.)
-    // Round 5 -- two-slice split-K of the duo kernel (gemm_bf16_duo.hip) where twice as many half-length workgroups fill the
-    // 512 slots better: cost in rounds x length, + 0.08 for the slab hand-over.  M = 5 496: fc2 / proj 232 -> 464 workgroups
-    // (1 x 1.0 -> 1 x 0.5), qkv 696 -> 1 392 (2 x 1.0 -> 3 x 0.5); fc1 (928 -> 1 856: 2.0 vs 2.0) stays.  Needs the caller's
-    // workspace (iggt_gemm_*_ws).  IGGT_GEMM_SPLITK=0: never.
-    static int sk_on = -1;
-    if (sk_on < 0) {
-        const char* e = getenv("IGGT_GEMM_SPLITK");
-        sk_on = (e && e[0] == '0') ? 0 : 1;
-    }
-    bool splitk = false;
-    if (sk_on && ws != nullptr && ((uintptr_t)ws % 256) == 0 && p.rows_in == 0) {
-        const long t = rows == 192 ? t192 : duo_tiles;
-        const double plain = (double)((t + slots - 1) / slots), split = 0.5 * (double)((2 * t + slots - 1) / slots) + 0.08;
-        if (split < plain && ws_bytes >= iggt_gemm_duo_splitk_bytes(M, N, rows)) {
-            splitk = true;
-            p.sk_err = (int*)ws;
-            p.sk_words = (int*)((char*)ws + 64);
-            p.sk_slab = (float*)((char*)ws + 64 + 4096 * 8);
-        }
-    }
-    // (with the split, proj -- K = N = 1 024: 232 workgroups of K = 1 024 or 344 tiles of the 128^2 kernel -- becomes 464
-    //  half-length workgroups of the duo kernel as well)
-    const bool duo_split = duo == 2 && splitk && M >= 1024 && M < 8192;
-    if (!(duo == 1 || duo_auto || duo_split)) splitk = false;
-    if ((duo == 1 || duo_auto || duo_split) && M >= 512 && (N % 128) == 0 && force_small_tile() == 0) {
-        const int rc = iggt_launch_gemm_duo(p, fmt, rows, (hipStream_t)stream, splitk);
+    // (Round 5's two-slice split-K of the duo kernel measured slower at every per-rank shape and was removed in round 6.)
+    if ((duo == 1 || duo_auto) && M >= 512 && (N % 128) == 0 && force_small_tile() == 0) {
+        const int rc = iggt_launch_gemm_duo(p, fmt, rows, (hipStream_t)stream);
         if (rc == 0) {
             IGGT_CHECK_LAUNCH();
             return 0;
@@ -487,30 +463,4 @@ extern "C" int iggt_gemm_f16(const void* A, long lda, const void* W, long ldw, i
                              int rows_in, int rows_out, int row_off, void* stream) {
     return gemm_h16(FMT_F16, A, lda, W, ldw, M, N, K, bias, gamma, add_table, out, ldo, out_is_f32, accumulate, act,
                     rows_in, rows_out, row_off, stream);
-}
-
-/* The same GEMMs with a caller-owned workspace that lets the dispatcher split K over two workgroups per output tile where that
- * fills the chip better (small grids: the per-rank shapes of a sharded run).  ws: 256-byte aligned; its first 64 + 32 768 bytes
- * must be ZERO before the first call (afterwards the kernels leave them zero); one workspace per stream. */
-extern "C" int iggt_gemm_bf16_ws(const void* A, long lda, const void* W, long ldw, int M, int N, int K,
-                                 const float* bias, const float* gamma, const float* add_table,
-                                 void* out, long ldo, int out_is_f32, int accumulate, int act,
-                                 int rows_in, int rows_out, int row_off, void* ws, long ws_bytes, void* stream) {
-    return gemm_h16(FMT_BF16, A, lda, W, ldw, M, N, K, bias, gamma, add_table, out, ldo, out_is_f32, accumulate, act,
-                    rows_in, rows_out, row_off, stream, ws, ws_bytes);
-}
-
-extern "C" int iggt_gemm_f16_ws(const void* A, long lda, const void* W, long ldw, int M, int N, int K,
-                                const float* bias, const float* gamma, const float* add_table,
-                                void* out, long ldo, int out_is_f32, int accumulate, int act,
-                                int rows_in, int rows_out, int row_off, void* ws, long ws_bytes, void* stream) {
-    return gemm_h16(FMT_F16, A, lda, W, ldw, M, N, K, bias, gamma, add_table, out, ldo, out_is_f32, accumulate, act,
-                    rows_in, rows_out, row_off, stream, ws, ws_bytes);
-}
-
-/* bytes of workspace iggt_gemm_*_ws can use for an (M, N) problem (the larger of the two tile heights) */
-extern "C" long iggt_gemm_ws_bytes(int M, int N) {
-    if (M <= 0 || N <= 0 || (N % 128) != 0) return 0;
-    const long a = iggt_gemm_duo_splitk_bytes(M, N, 192), b = iggt_gemm_duo_splitk_bytes(M, N, 256);
-    return a > b ? a : b;
 }

@@ -40,20 +40,11 @@ IGGT_DEVINL void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Round 5 -- two-slice split-K (template parameter SPLITK; review item "build, don't price").  At M = 5 496 (one rank of an
-// 8-GPU run) fc2 / proj are 232 workgroups -- one per CU, nothing beside their epilogues -- and qkv is 696 = two rounds of the 512
-// slots with the second 36 % full.  With SPLITK every output tile is computed by TWO workgroups over half of K each (work item
-// = (tile, slice), slice fastest, so both sit in the same XCD chunk of the remapped order -- speed only).  Hand-over
-// (cdna_hip_programming.md Guideline 16, ticket form): at the end of its K loop a workgroup draws a ticket for its tile;
-//   ticket 0 (first arriver): writes its accumulators to the tile's fp32 slab in REGISTER order (each wave instruction stores
-//     1 KiB contiguous; the reducer has the same lane <-> element map, so no transposition), every wave drains its stores, barrier,
-//     lane 0: agent-scope release fence, drain again, relaxed agent-scope store of the "slab ready" word; exits.
-//   ticket 1 (second arriver): lane 0 polls the ready word (relaxed, bounded), agent-scope acquire fence, resets both words for
-//     the next launch, barrier; all threads add the slab to their accumulators with plain 16-byte loads and run the epilogue.
-// The waiting workgroup only ever waits for one that has ARRIVED (it is running and needs nothing to finish): no assumption about
-// dispatch order or co-residency.  Which slice reduces varies from run to run, the result does not: a + b is commutative, so the
-// accumulator sum -- and everything the epilogue derives from it -- is bitwise the same either way.
-template <int MODE, int FMT, int TM, bool SPLITK = false>
+// Round 5 built a two-slice split-K of this kernel (ticket + fp32 slab hand-over); it measured slower at every per-rank shape (qkv
+// 61 -> 93 us: pipeline fill and epilogue do not halve with K) and was removed in round 6 (profiles/r05_gemm_splitk_ab.txt, git history).
+// Round 6 -- GELU from the LDS table of gemm_bf16_t256.hip (template parameter LUT; fc1 on the 192-row tiles, whose two 60-KiB
+// rings leave 40 KiB of the CU's LDS free: 2 x (60 + 16.4) KiB fit; the 256-row variant's 2 x 72 KiB do not).
+template <int MODE, int FMT, int TM, bool LUT = false>
 __global__ __launch_bounds__(256, 2) void gemm_h16_duo_kernel(const GemmParams p) {
     static_assert(TM == 256 || TM == 192, "row tile");
     constexpr int A_BYTES = TM * TK * 2;            // 16 | 12 KiB
@@ -65,12 +56,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_duo_kernel(const GemmParams p
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    int v = xcd_remap(blockIdx.x, gridDim.x);
-    int slice = 0;
-    if constexpr (SPLITK) {
-        slice = v & 1;
-        v >>= 1;
-    }
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
     if (p.group_m > 1) {   // groups of group_m row tiles, m fastest inside a group (see gemm_bf16_t256.hip)
         const int per_group = p.group_m * p.tiles_n;
@@ -103,15 +89,13 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_duo_kernel(const GemmParams p
         rw = rw < p.N ? rw : p.N - 1;
         w_off[i] = rw * (int)p.ldw + (c_pos ^ ((r >> 2) & 3)) * 8;
     }
-    const int KT_all = p.K / TK;                      // >= 3 per slice (launcher)
-    const int KT = SPLITK ? KT_all / 2 : KT_all;
-    const int kbase = SPLITK ? slice * KT * TK : 0;    // first K column of this slice; `kt` below counts from it
+    const int KT = p.K / TK;                          // >= 3 (launcher)
     auto dma_a = [&](int kt, int i) {
-        __builtin_amdgcn_global_load_lds((gptr_t*)(p.A + a_off[i] + kbase + kt * TK),
+        __builtin_amdgcn_global_load_lds((gptr_t*)(p.A + a_off[i] + kt * TK),
                                          (lptr_t*)(smem + (kt % NSTAGE) * STAGE_BYTES + (AC * wave + i) * 1024), 16, 0, 0);
     };
     auto dma_w = [&](int kt, int i) {
-        __builtin_amdgcn_global_load_lds((gptr_t*)(p.W + w_off[i] + kbase + kt * TK),
+        __builtin_amdgcn_global_load_lds((gptr_t*)(p.W + w_off[i] + kt * TK),
                                          (lptr_t*)(smem + (kt % NSTAGE) * STAGE_BYTES + A_BYTES + (2 * wave + i) * 1024), 16, 0, 0);
     };
     auto dma_stage = [&](int kt) {
@@ -137,6 +121,8 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_duo_kernel(const GemmParams p
 
     dma_stage(0);
     dma_stage(1);
+    float2* lut = reinterpret_cast<float2*>(smem + NSTAGE * STAGE_BYTES);   // behind the ring (LUT builds only)
+    if constexpr (LUT) gelu_lut_build(lut, tid, 256);   // while the first stages are in flight
     wait_vm<AC + 2>();
     __builtin_amdgcn_s_barrier();
 
@@ -174,59 +160,6 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_duo_kernel(const GemmParams p
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    if constexpr (SPLITK) {
-        const int tile = tm * p.tiles_n + tn;
-        int* words = p.sk_words + 2 * tile;
-        f32x4* slab = reinterpret_cast<f32x4*>(p.sk_slab + (long)tile * (TM * TN)) + (wave * (MI * 2 * 4)) * 64 + lane;
-        int* sh = reinterpret_cast<int*>(smem);      // the ring is free: every wave left the K loop through its last barrier
-        if (tid == 0) sh[0] = __hip_atomic_fetch_add(&words[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const int ticket = sh[0];
-        __syncthreads();                             // (the epilogue below reuses smem)
-        if (ticket == 0) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        f32x4 t = {acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]};
-                        slab[((i * 2 + j) * 4 + r4) * 64] = t;
-                    }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&words[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
-        }
-        if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(&words[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                if (++spins > (1 << 22)) {           // ~ a second: the partner is gone (never on a healthy device); say so
-                    __hip_atomic_store(p.sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(&words[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
-            __hip_atomic_store(&words[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const f32x4 t = slab[((i * 2 + j) * 4 + r4) * 64];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += t[e];
-                }
-    }
     // ---- epilogue: two HALF-row phases through LDS as fp32 [HALF][128] (64 of the 72 | 48 of the 60 KiB), 16-byte row segments ----
     float* stile = reinterpret_cast<float*>(smem);
     const int c4 = tid & 31, r0 = tid >> 5;          // 32 threads x 4 columns, 8 rows per pass
@@ -268,7 +201,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_duo_kernel(const GemmParams p
             } else if constexpr (MODE == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v4[e] += bias4[e];
-                if (p.act == 1) {
+                if constexpr (LUT) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = gelu_lut(v4[e], lut);
+                } else if (p.act == 1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v4[e] = gelu_erf(v4[e]);
                 } else if (p.act == 2) {
@@ -290,26 +226,35 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_duo_kernel(const GemmParams p
 }
 
 template <int FMT, int TM>
-int launch_duo(const GemmParams& p, int mode, hipStream_t stream, bool splitk) {
+int launch_duo(const GemmParams& p, int mode, hipStream_t stream) {
     const int lds = NSTAGE * (TM * TK * 2 + W_BYTES);  // 72 | 60 KiB: two workgroups per CU
+    static int gelu_lut_on = -1;                       // IGGT_GELU_LUT=0: the polynomial erfc epilogue (gemm_common.h gelu_erf)
+    if (gelu_lut_on < 0) {
+        const char* e = getenv("IGGT_GELU_LUT");
+        gelu_lut_on = (e && atoi(e) == 0) ? 0 : 1;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         const void* kernels[] = {(const void*)gemm_h16_duo_kernel<1, FMT, TM>, (const void*)gemm_h16_duo_kernel<2, FMT, TM>,
-                                 (const void*)gemm_h16_duo_kernel<3, FMT, TM>, (const void*)gemm_h16_duo_kernel<1, FMT, TM, true>,
-                                 (const void*)gemm_h16_duo_kernel<2, FMT, TM, true>};
+                                 (const void*)gemm_h16_duo_kernel<3, FMT, TM>};
         for (const void* k : kernels) {
             const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return (int)e;
         }
+        if constexpr (TM == 192) {
+            const hipError_t e = hipFuncSetAttribute((const void*)gemm_h16_duo_kernel<1, FMT, TM, true>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds + GELU_LUT_BYTES);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_set = true;
     }
-    if (splitk && mode != 3) {
-        const dim3 grid2(2 * p.tiles_m * p.tiles_n), block2(256);
-        if (mode == 1) hipLaunchKernelGGL((gemm_h16_duo_kernel<1, FMT, TM, true>), grid2, block2, lds, stream, p);
-        else hipLaunchKernelGGL((gemm_h16_duo_kernel<2, FMT, TM, true>), grid2, block2, lds, stream, p);
-        return 0;
-    }
     const dim3 grid(p.tiles_m * p.tiles_n), block(256);
+    if constexpr (TM == 192) {
+        if (mode == 1 && p.act == 1 && gelu_lut_on) {
+            hipLaunchKernelGGL((gemm_h16_duo_kernel<1, FMT, TM, true>), grid, block, lds + GELU_LUT_BYTES, stream, p);
+            return 0;
+        }
+    }
     if (mode == 1) hipLaunchKernelGGL((gemm_h16_duo_kernel<1, FMT, TM>), grid, block, lds, stream, p);
     else if (mode == 2) hipLaunchKernelGGL((gemm_h16_duo_kernel<2, FMT, TM>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((gemm_h16_duo_kernel<3, FMT, TM>), grid, block, lds, stream, p);
@@ -320,14 +265,7 @@ int launch_duo(const GemmParams& p, int mode, hipStream_t stream, bool splitk) {
 
 // rows: 256 | 192 rows per tile.  Returns -100 when the parameter combination is not covered (caller falls through to the
 // other kernels)
-constexpr long SK_HEAD = 64, SK_MAX_TILES = 4096;     // workspace: [err, pad][2 words per tile][slabs]
-
-long iggt_gemm_duo_splitk_bytes(int M, int N, int rows) {
-    const long tiles = (long)((M + rows - 1) / rows) * (N / TN);
-    return SK_HEAD + SK_MAX_TILES * 8 + tiles * rows * TN * 4;
-}
-
-int iggt_launch_gemm_duo(const GemmParams& p_in, int fmt, int rows, hipStream_t stream, bool splitk) {
+int iggt_launch_gemm_duo(const GemmParams& p_in, int fmt, int rows, hipStream_t stream) {
     GemmParams p = p_in;
     if (rows != 256 && rows != 192) return -100;
     if ((long)p.M * p.lda >= (1L << 31) || (long)p.N * p.ldw >= (1L << 31)) return -100;
@@ -346,10 +284,6 @@ int iggt_launch_gemm_duo(const GemmParams& p_in, int fmt, int rows, hipStream_t 
     else if (p.out_f32 && p.accumulate && p.rows_in == 0 && p.act == 0) mode = 2;
     else if (p.out_f32 && !p.accumulate && p.act == 0 && !p.gamma) mode = 3;
     else return -100;
-    if (splitk) {   // both slices need the pipeline's three stages, an even split, and a tile count the word table holds
-        if (mode == 3 || p.sk_words == nullptr || (p.K / TK) % 2 != 0 || p.K / TK / 2 < 3 ||
-            (long)p.tiles_m * p.tiles_n > SK_MAX_TILES) splitk = false;
-    }
-    if (rows == 192) return fmt == FMT_F16 ? launch_duo<FMT_F16, 192>(p, mode, stream, splitk) : launch_duo<FMT_BF16, 192>(p, mode, stream, splitk);
-    return fmt == FMT_F16 ? launch_duo<FMT_F16, 256>(p, mode, stream, splitk) : launch_duo<FMT_BF16, 256>(p, mode, stream, splitk);
+    if (rows == 192) return fmt == FMT_F16 ? launch_duo<FMT_F16, 192>(p, mode, stream) : launch_duo<FMT_BF16, 192>(p, mode, stream);
+    return fmt == FMT_F16 ? launch_duo<FMT_F16, 256>(p, mode, stream) : launch_duo<FMT_BF16, 256>(p, mode, stream);
 }

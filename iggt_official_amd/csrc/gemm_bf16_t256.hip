@@ -64,17 +64,7 @@ IGGT_DEVINL void wait_vmcnt() {
 // exact erff, no memory traffic -- and the epilogue evaluates gelu(x) = x (f_i + frac * d_i): fma, med3, floor, sub, cvt,
 // ds_read_b64, fma, mul per element.  |error| <= 2.5e-6 absolute (1e-4 of the value in the negative tail, where fp16's own
 // rounding is 4.9e-4), tests/test_kernels_f16_gpu.py gates it against torch's erf GELU at the kernel tolerance.
-constexpr int LUT_N = 2048;
-constexpr float LUT_SCALE = 128.f, LUT_OFF = 1024.f;
-constexpr int LUT_BYTES = (LUT_N + 1) * 8;
-
-IGGT_DEVINL float gelu_lut(float x, const float2* lut) {
-    float t = fmaf(x, LUT_SCALE, LUT_OFF);
-    t = __builtin_amdgcn_fmed3f(t, 0.f, 2047.996f);   // x <= -8: Phi = 6e-16; x >= 8: Phi = 1 to fp32
-    const float fi = floorf(t);
-    const float2 e = lut[(int)fi];
-    return x * fmaf(t - fi, e.y, e.x);
-}
+constexpr int LUT_BYTES = GELU_LUT_BYTES;   // table + helpers: gemm_common.h (shared with the 192-row duo kernel)
 
 template <int MODE, int DBG, int FMT, bool LUT = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_t256pp_kernel(const GemmParams p) {
@@ -180,17 +170,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256pp_kernel(const GemmPara
     dma_half(1, 0);
     dma_half(1, 1);
     dma_half(2, 0);
-    if constexpr (LUT) {   // while the first stages are in flight: 4 table entries per thread (+ the guard entry)
-        float f[5];
-#pragma unroll
-        for (int e = 0; e < 5; ++e) {
-            const float x = (float)(tid * 4 + e - (int)LUT_OFF) * (1.0f / LUT_SCALE);
-            f[e] = 0.5f + 0.5f * erff(x * 0.70710678118654752440f);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) lut[tid * 4 + e] = make_float2(f[e], f[e + 1] - f[e]);
-        if (tid == 0) lut[LUT_N] = make_float2(1.0f, 0.0f);
-    }
+    if constexpr (LUT) gelu_lut_build(lut, tid, 512);   // while the first stages are in flight: 4 table entries per thread
     wait_vmcnt<6>();
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();  // the wm = 1 waves run one barrier behind

@@ -19,12 +19,6 @@ struct GemmParams {
     int accumulate;  // out_f32 += value
     int act;         // 0 none, 1 exact GELU, 2 ReLU
     int rows_in, rows_out, row_off;  // output row remap (rows_in == 0: identity)
-    // two-slice split-K of the 256 x 128 two-workgroups-per-CU kernel (gemm_bf16_duo.hip, round 5): per output tile two int32
-    // words {ticket, slab ready} (zero between launches: the last arriver resets them) and one fp32 slab of the tile's
-    // accumulators in register order; sk_err: one int32 that a workgroup sets when its bounded wait ran out.  nullptr: no split
-    int* sk_words;
-    float* sk_slab;
-    int* sk_err;
 };
 
 // Exact (erf) GELU, nn.GELU() of mlp.py:34.  erfc(|x|/sqrt2) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below
@@ -40,6 +34,36 @@ IGGT_DEVINL float gelu_erf(float x) {
     poly = fmaf(poly, t, 0.254829592f);
     const float half_e = 0.5f * poly * t * __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
     return x >= 0.f ? fmaf(-x, half_e, x) : x * half_e;
+}
+
+// GELU from an LDS table (round 4, gemm_bf16_t256.hip; round 6 also the 192-row duo kernel): 2 048 intervals of
+// Phi(x) = (1 + erf(x / sqrt 2)) / 2 over [-8, 8) as (value, forward difference) pairs, built per workgroup through the exact erff
+// while its first DMA stages are in flight; gelu(x) = x (f_i + frac d_i): fma, med3, floor, sub, cvt, ds_read_b64, fma, mul.
+// |error| <= 2.5e-6 absolute (tests/test_kernels_f16_gpu.py test_gemm_gelu_table_against_erf).
+constexpr int GELU_LUT_N = 2048;
+constexpr float GELU_LUT_SCALE = 128.f, GELU_LUT_OFF = 1024.f;
+constexpr int GELU_LUT_BYTES = (GELU_LUT_N + 1) * 8;
+
+IGGT_DEVINL float gelu_lut(float x, const float2* lut) {
+    float t = fmaf(x, GELU_LUT_SCALE, GELU_LUT_OFF);
+    t = __builtin_amdgcn_fmed3f(t, 0.f, 2047.996f);   // x <= -8: Phi = 6e-16; x >= 8: Phi = 1 to fp32
+    const float fi = floorf(t);
+    const float2 e = lut[(int)fi];
+    return x * fmaf(t - fi, e.y, e.x);
+}
+
+// every thread of an `nthreads`-thread workgroup fills its GELU_LUT_N / nthreads entries (+ the guard entry); the caller's next
+// barrier publishes the table
+IGGT_DEVINL void gelu_lut_build(float2* lut, int tid, int nthreads) {
+    const int per = GELU_LUT_N / nthreads;
+    float prev = 0.5f + 0.5f * erff((float)(tid * per - (int)GELU_LUT_OFF) * (1.0f / GELU_LUT_SCALE) * 0.70710678118654752440f);
+    for (int e = 0; e < per; ++e) {
+        const float x1 = (float)(tid * per + e + 1 - (int)GELU_LUT_OFF) * (1.0f / GELU_LUT_SCALE);
+        const float next = 0.5f + 0.5f * erff(x1 * 0.70710678118654752440f);
+        lut[tid * per + e] = make_float2(prev, next - prev);
+        prev = next;
+    }
+    if (tid == 0) lut[GELU_LUT_N] = make_float2(1.0f, 0.0f);
 }
 
 // Epilogue of one 32x32 accumulator fragment whose top-left element is (m_base, n - (lane & 31)):
@@ -123,7 +147,4 @@ IGGT_DEVINL void gemm_epilogue_row4_nobias(const GemmParams& p, f32x4 v, int m, 
 // returns -100 when the parameter combination has no specialised big-tile kernel (caller falls back)
 int iggt_launch_gemm_t256(const GemmParams& p, int fmt, hipStream_t stream);
 // 256 x 128 tile, two workgroups per CU (gemm_bf16_duo.hip); same return convention
-int iggt_launch_gemm_duo(const GemmParams& p, int fmt, int rows, hipStream_t stream, bool splitk = false);
-// bytes of split-K workspace the duo kernel needs for (M, N) at `rows` rows per tile; layout: [err int32, pad to 64 B][2 int32 per
-// tile, padded to 256 B][fp32 slabs]
-long iggt_gemm_duo_splitk_bytes(int M, int N, int rows);
+int iggt_launch_gemm_duo(const GemmParams& p, int fmt, int rows, hipStream_t stream);

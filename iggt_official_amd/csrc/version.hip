@@ -1,2 +1,2 @@
 #include "../../include/iggt_hip.h"
-extern "C" int iggt_hip_abi_version(void) { return 25; }
+extern "C" int iggt_hip_abi_version(void) { return 26; }

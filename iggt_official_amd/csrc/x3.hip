@@ -438,6 +438,9 @@ extern "C" int iggt_qkv_split_f16(const float* qkv, long ld_in, void* q_out, lon
     if ((qw == nullptr) != (kw == nullptr) || (qw != nullptr && (qb == nullptr || kb == nullptr))) return -3;
     if ((cos_t == nullptr) != (sin_t == nullptr) || (cos_t != nullptr && (P <= 0 || gw <= 0))) return -3;
     if (((uintptr_t)cos_t | (uintptr_t)sin_t) % 16) return -2;   // the tables are read as 16-byte vectors
+    // the kernel reads qkv and writes q / k / v (and their lo halves) as 16-byte vectors over a fixed [3 x 16 heads x 64] row
+    if (((uintptr_t)qkv | (uintptr_t)q_out | (uintptr_t)k_out | (uintptr_t)v_out) % 16) return -2;
+    if (ld_in < 3072 || ldq < 1024 || ldk < 1024 || ldv < 1024) return -2;
     QkvSplitParams p;
     p.qkv = qkv; p.ld_in = ld_in;
     p.q_out = (bf16_t*)q_out; p.ldq = ldq; p.q_lo = q_lo;

@@ -180,6 +180,15 @@ class ViewShard:
             self._events.append(torch.cuda.Event())
         return self._events[i]
 
+    def agree_any(self, flags: List[int], device) -> List[int]:
+        """Element-wise OR of a small list of 0 / 1 host flags over all ranks (one int32 all-reduce MAX on `device`, read back:
+        synchronises).  Host decisions that change WHICH launches / how many warm-up forwards a rank issues must be identical
+        on every rank -- every forward issues collectives (models/aggregator.py _apply_guard_snapshot)."""
+        t = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32, device=device)
+        if self.world > 1 or self.force:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t.tolist()
+
     def all_gather_rows(self, x_local: torch.Tensor) -> torch.Tensor:
         """[n_l, ...] -> [world*n_l, ...] (camera tokens, small outputs)."""
         src = self._buf("rows_in", tuple(x_local.shape), x_local)

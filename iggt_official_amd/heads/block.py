@@ -9,7 +9,7 @@ projection outputs: no head transposes); the q/k/v/proj Linear layers run on the
 import torch
 import torch.nn as nn
 
-from .. import _C
+from .. import _C, profiling
 from . import tokenops as tk
 
 
@@ -59,8 +59,9 @@ class CrossAttention(nn.Module):
         k = tk.linear(self.projk, key)
         v = tk.linear(self.projv, value)
         o = torch.empty(B, Nq, C, dtype=torch.float32, device=q.device)
-        _C.attn_f32(q, k, v, o, B, self.num_heads, Nq, Nk, self.head_dim, Nq * C, C, Nk * C, C, Nk * C, C, Nq * C, C,
-                    self.scale)
+        with profiling.region("cross_attn", ("fp32 MFMA", 4.0 * B * Nq * Nk * C)):     # (kind, algorithmic FLOPs)
+            _C.attn_f32(q, k, v, o, B, self.num_heads, Nq, Nk, self.head_dim, Nq * C, C, Nk * C, C, Nk * C, C, Nq * C, C,
+                        self.scale)
         return tk.linear(self.proj, o)
 
 

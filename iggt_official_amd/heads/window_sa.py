@@ -22,7 +22,7 @@ PyTorch-ROCm ops: OCAB's query scramble (one permuted copy), CAB's squeeze-excit
 import torch
 import torch.nn as nn
 
-from .. import _C
+from .. import _C, profiling
 from . import convops as co
 from . import tokenops as tk
 from .block import MemEffAttention
@@ -136,8 +136,10 @@ class HAB(nn.Module):
         # kernel gathers the 8x8 windows itself (no window_partition / window_reverse copies)
         qkv = tk.linear(self.attn.qkv, y)                                                  # [b, h, w, 3c]
         o = torch.empty(b, h, w, c, dtype=torch.float32, device=x.device)
-        _C.window_attn(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], o, self.attn.num_heads, self.attn.head_dim,
-                       self.attn.scale)
+        # bench.py's part-branch leg: (kind, algorithmic FLOPs = 4 x windows x heads x 64 queries x keys x head dim)
+        with profiling.region("window_attn", ("HAB 8x8 self", 4.0 * b * (h // 8) * (w // 8) * 64 * 64 * c)):
+            _C.window_attn(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], o, self.attn.num_heads, self.attn.head_dim,
+                           self.attn.scale)
         att = tk.linear(self.attn.proj, o).view(b, h * w, c)
         x = x + att + conv_x * self.conv_scale
         return self.mlp(tk.layer_norm(self.norm2, x), res=x)
@@ -189,7 +191,8 @@ class OCAB(nn.Module):
         o = torch.empty(b, h, w, c, dtype=torch.float32, device=x.device)
         # keys / values: 12x12 windows at stride 8 read in place from the maps (zero vectors outside the image, like
         # nn.Unfold's padding); output written at the regular window positions (= window_reverse)
-        _C.window_attn(qw, kk, vv, o, nh, d, self.scale, q_windows=True, ow=ow, pad=pad, bias=bias)
+        with profiling.region("window_attn", ("OCAB 8x8 x 12x12 cross", 4.0 * b * (h // 8) * (w // 8) * 64 * ow * ow * c)):
+            _C.window_attn(qw, kk, vv, o, nh, d, self.scale, q_windows=True, ow=ow, pad=pad, bias=bias)
         x = tk.linear(self.proj, o.view(b, h * w, c), res=shortcut)
         return self.mlp(tk.layer_norm(self.norm2, x), res=x)
 

@@ -88,27 +88,6 @@ class Workspace:
             self._bufs[name] = cur
         return cur[:n].view(*shape)
 
-    def get_zeroed(self, name, n, dtype, device):
-        """Flat buffer of n elements that is zero-filled when it is (re)allocated and never touched by this class again (the
-        split-K words of the GEMM dispatcher: the kernels leave them zero)."""
-        cur = self._bufs.get(name)
-        if cur is None or cur.numel() < n or cur.dtype != dtype or cur.device != device:
-            if cur is not None:
-                graphs.buffers_changed()
-            cur = torch.zeros(n, dtype=dtype, device=device)
-            self._bufs[name] = cur
-        return cur
-
-    def gemm_splitk(self, T, N, device):
-        """Workspace that lets _C.gemm_h16 split K over two workgroups per tile (include/iggt_hip.h iggt_gemm_*_ws): only where the
-        dispatcher can use it -- the two-workgroups-per-CU kernel's range of M (the per-rank shapes of a sharded run)."""
-        # OFF by default -- built and measured in round 5 (profiles/r05_gemm_splitk_ab.txt, M = 5 496): qkv 61 -> 93 us, proj 27 -> 41,
-        # fc2 75.5 -> 80: at K = 1 024 the K loop is only half of a workgroup's time (pipeline fill + epilogue do not halve), at
-        # K = 4 096 two co-resident half-K workgroups gain less than the slab hand-over costs.  IGGT_GEMM_SPLITK=1 turns it on.
-        if not GEMM_SPLITK or not (1024 <= T < 8192):
-            return None
-        return self.get_zeroed("gemm_sk", _C.gemm_ws_bytes(T, N), torch.uint8, device)
-
     def get_padded(self, name, rows, cols, dtype, device, pad=ROW_PAD):
         """[rows, cols] view with a row stride of cols + pad elements (see ROW_PAD)."""
         return self.get(name, (rows, cols + pad), dtype, device)[:, :cols]
@@ -129,7 +108,6 @@ def _h16_residual(w: torch.Tensor, dt: torch.dtype):
     return (w - w.to(dt).float()).to(dt).contiguous()
 
 
-GEMM_SPLITK = __import__("os").environ.get("IGGT_GEMM_SPLITK", "0") == "1"
 GEMM_MAX_OPERAND_ELEMENTS = 1 << 31   # csrc/gemm_bf16_t256.hip, gemm_bf16_duo.hip: M x lda and N x ldw below this
 
 
@@ -414,11 +392,10 @@ class Block(nn.Module):
         hid = ws.get("hid" + alt, (T, pk["w_fc1"].shape[0]), dt, dev)
 
         sat = precision.debug_saturation()
-        gsk = ws.gemm_splitk(T, 3 * C, dev)         # None unless IGGT_GEMM_SPLITK=1 (measured slower: see Workspace.gemm_splitk)
         _C.layernorm(x2d, pk["n1w"], pk["n1b"], xn, self.norm1.eps)
         b_ = compensated_bias(ws, xn, pk["dw_qkv"], pk["b_qkv"])
         with profiling.region("gemm", ("qkv", T, 3 * C, C)):       # bench.py's secondary roofline leg: (name, M, N, K)
-            _C.gemm_h16(xn, pk["w_qkv"], qkv, bias=b_, ws=gsk)
+            _C.gemm_h16(xn, pk["w_qkv"], qkv, bias=b_)
         if sat:
             precision.count_saturation("norm1", xn)
             precision.count_saturation("qkv", qkv)
@@ -522,7 +499,7 @@ class Block(nn.Module):
             precision.count_saturation("attn_out", ao)
         b_ = compensated_bias(ws, ao, pk["dw_proj"], pk["b_proj"])
         with profiling.region("gemm", ("proj", T, C, C)):
-            _C.gemm_h16(ao, pk["w_proj"], x2d, bias=b_, gamma=pk["g1"], accumulate=True, ws=gsk)
+            _C.gemm_h16(ao, pk["w_proj"], x2d, bias=b_, gamma=pk["g1"], accumulate=True)
         _C.layernorm(x2d, pk["n2w"], pk["n2b"], xn, self.norm2.eps)
         b_ = compensated_bias(ws, xn, pk["dw_fc1"], pk["b_fc1"])
         with profiling.region("gemm", ("fc1", T, hid.shape[1], C)):
@@ -532,7 +509,7 @@ class Block(nn.Module):
             precision.count_saturation("mlp_hidden", hid)
         b_ = compensated_bias(ws, hid, pk["dw_fc2"], pk["b_fc2"])
         with profiling.region("gemm", ("fc2", T, C, hid.shape[1])):
-            _C.gemm_h16(hid, pk["w_fc2"], x2d, bias=b_, gamma=pk["g2"], accumulate=True, ws=gsk)
+            _C.gemm_h16(hid, pk["w_fc2"], x2d, bias=b_, gamma=pk["g2"], accumulate=True)
         return x2d
 
     def _forward_x3(self, x2d, ws, pk, *, batch, tokens, rope_geom, kv_gather):

@@ -177,24 +177,39 @@ class Aggregator(nn.Module):
         self._guard_snap = (host, ev, [b for b, _ in gs], [g for _, g in gs])
 
     def _apply_guard_snapshot(self):
+        from .. import graphs, precision
+
         snap, self._guard_snap = self._guard_snap, None
-        if snap is None or torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing():
             self._guard_snap = snap
             return
-        host, ev, blocks, guards = snap
-        if not ev.query():          # not there yet (the host runs ahead of the device): keep it for the next forward
-            self._guard_snap = snap
-            return
+        sharded = self.shard is not None and self.shard.active
+        every = list(self.frame_blocks) + list(self.global_blocks)
+        want = [False] * len(every)          # per block (positional: the same index on every rank): turn the launches on
+        if snap is not None:
+            host, ev, blocks, guards = snap
+            if ev.query():
+                pos = {id(b): i for i, b in enumerate(every)}
+                for i, (b, g) in enumerate(zip(blocks, guards)):
+                    if int(host[i, 1]) != 0 and not b._est_on and b.attn_guard() is g:     # flagged tiles, or skipped
+                        want[pos[id(b)]] = True
+            else:                   # not there yet (the host runs ahead of the device): keep it for the next forward
+                self._guard_snap = snap
+        if sharded and precision.attn_estimated_shift():
+            # View-sharded: a rank-LOCAL decision here would invalidate the captured graphs of that rank alone (buffers_changed
+            # below) -- it would then re-run its warm-up forwards and a capture, each issuing collectives, while its peers replay
+            # (ADVICE r5).  So the ranks agree: a block takes the estimated-shift launches on every rank as soon as any rank's
+            # norm-bound kernel flagged tiles there.  One 48-word all-reduce per EAGER forward (replays never come here); it
+            # reads the result back, which an eager sharded forward -- warm-up or debugging -- can afford.
+            want = [bool(w) for w in self.shard.agree_any(want, self.camera_token.device)]
         changed = False
-        for i, (b, g) in enumerate(zip(blocks, guards)):
-            flagged_or_skipped = int(host[i, 1]) != 0
-            if flagged_or_skipped and not b._est_on and b.attn_guard() is g:
+        for b, w in zip(every, want):
+            g = b.attn_guard()
+            if w and not b._est_on and g is not None:
                 b._est_on = True
                 g.copy_(torch.tensor([0, 0, 0, 0, 1, 0, 0, 0], dtype=torch.int32), non_blocking=True)   # estimated mode, armed
                 changed = True
         if changed:
-            from .. import graphs
-
             graphs.buffers_changed()    # captured graphs do not hold the estimated-shift launches of these blocks: re-capture
 
     def reset_guards(self):

@@ -32,7 +32,7 @@ except Exception:  # pragma: no cover
 
 import os
 
-from .. import _C, precision
+from .. import _C, precision, profiling
 from ..dist import ViewShard
 from ..graphs import GraphCache
 from ..heads import convops
@@ -281,9 +281,11 @@ class IGGT(_Base):
         pts, conf, point_feat = self.point_head(tokens, images=images, patch_start_idx=psi)
         pred["world_points"], pred["world_points_conf"] = pts, conf
         if part_ok:
-            pyramid, _ = self.part_adaptor(tokens, images=images, patch_start_idx=psi)
-            pred["part_feat"] = self.part_head(list(pyramid.values()), point_feature=point_feat, images=images,
-                                               patch_start_idx=psi)
+            # the instance-feature branch (reference vggt.py:204-218); bench.py times it as a whole and per kernel family
+            with profiling.tagged("part"), profiling.region("part_branch", None):
+                pyramid, _ = self.part_adaptor(tokens, images=images, patch_start_idx=psi)
+                pred["part_feat"] = self.part_head(list(pyramid.values()), point_feature=point_feat, images=images,
+                                                   patch_start_idx=psi)
         self._track(pred, tokens, images, psi, query_points)
         self._join_heads()
         self._join_camera()

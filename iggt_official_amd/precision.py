@@ -226,6 +226,12 @@ def escalation() -> str:
     return _escalate if _operand == torch.float16 else "off"
 
 
+def escalation_policy() -> str:
+    """The policy as set (IGGT_ESCALATE / set_escalation), whatever the operand format: what a caller that switches the rung off
+    for a comparison forward has to restore."""
+    return _escalate
+
+
 def set_escalation(mode: str) -> None:
     global _escalate
     if mode not in ("auto", "off", "all"):

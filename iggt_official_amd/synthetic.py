@@ -92,7 +92,12 @@ def hash_lognormal(n: int, key: int, device="cpu", sigma: float = 1.0) -> torch.
 # "trained_like" takes its knobs from the mode string itself, so that a fixture's meta["mode"] names them all:
 #   trained_like                      = the defaults below
 #   trained_like(qk=0.5,tok=10)       = overrides
-_TL_DEFAULTS = dict(qk=1.0, norm=1.0, tok=30.0, col=8.0, colfrac=1e-3, gauss=1.0)
+# Round 6 -- OUTLIER CHANNELS (what trained ViTs, DINOv2 included, are known for, as opposed to a heavy tail over ALL channels):
+#   out=K, outmag=M   K channels of every norm1 / norm2 scale are multiplied by M (K = 1, M = 10: "one gamma = 10 among 1 023 of ~1");
+#   outshare=1        the SAME K channels in every block (0: each LayerNorm draws its own);
+#   massive=A         (with outshare=1) rows of every mlp.fc2 weight / bias that write those channels are multiplied by A: the
+#                     residual stream then carries "massive activations" on them, which every later LayerNorm sees.
+_TL_DEFAULTS = dict(qk=1.0, norm=1.0, tok=30.0, col=8.0, colfrac=1e-3, gauss=1.0, out=0.0, outmag=10.0, outshare=0.0, massive=1.0)
 
 
 def trained_like_options(mode: str) -> dict:
@@ -105,6 +110,13 @@ def trained_like_options(mode: str) -> dict:
                 raise ValueError(f"unknown trained_like option {k!r}")
             o[k] = float(v)
     return o
+
+
+def outlier_channels(name: str, C: int, seed: int, o: dict, device="cpu") -> torch.Tensor:
+    """The K outlier channel indices (int64 [K]) of the LayerNorm / fc2 tensor `name` (see _TL_DEFAULTS)."""
+    K = int(o["out"])
+    src = "#outlier-channels" if o["outshare"] else name.rsplit(".", 1)[0] + "#outlier-channels"
+    return (hash_uniform(K, _name_seed(src, seed), device) * float(C)).floor().to(torch.int64)
 
 
 def make_tensor(name: str, shape, seed: int, mode: str, device="cpu") -> torch.Tensor:
@@ -132,8 +144,18 @@ def make_tensor(name: str, shape, seed: int, mode: str, device="cpu") -> torch.T
         if leaf == "weight" and len(shape) == 1:
             parent = name.split(".")[-2]
             sig = o["qk"] if parent in ("q_norm", "k_norm") else o["norm"] if parent in ("norm1", "norm2") else 0.0
+            if parent in ("norm1", "norm2") and o["out"] >= 1.0:
+                w = hash_lognormal(n, key, device, sig).view(shape) if sig > 0.0 else one_plus(0.1)
+                w[outlier_channels(name, n, seed, o, device)] *= o["outmag"]
+                return w
             if sig > 0.0:
                 return hash_lognormal(n, key, device, sig).view(shape)
+        if (o["massive"] != 1.0 and o["outshare"] and o["out"] >= 1.0 and ".mlp.fc2." in name and ".blocks." in name.replace("_blocks.", ".blocks.")
+                and shape[0] == 1024):
+            base = make_tensor(name, shape, seed, mode.split("(")[0] + "(" + ",".join(
+                f"{k}={v}" for k, v in o.items() if k != "massive") + ")", device)
+            base[outlier_channels(name, shape[0], seed, o, device)] *= o["massive"]
+            return base
         if leaf in ("camera_token", "register_token") and o["tok"] > 0.0:
             return (hash_normal(n, key, device) * o["tok"]).view(shape)
         if leaf == "weight" and len(shape) >= 2 and not name.endswith("updateformer.flow_head.weight") and o["gauss"]:

@@ -44,22 +44,8 @@ int iggt_gemm_f16(const void* A, long lda, const void* W, long ldw, int M, int N
                   void* out, long ldo, int out_is_f32, int accumulate, int act,
                   int rows_in, int rows_out, int row_off, void* stream);
 
-/* ABI v25 (round 5): the same GEMMs with a caller-owned workspace.  Where twice as many half-length workgroups fill the chip
- * better (small grids: M of a few thousand rows, the per-rank shapes of a view-sharded run) the dispatcher computes every output
- * tile with TWO workgroups over half of K each; the second to finish adds the first one's accumulators (an fp32 slab in the
- * workspace, handed over by an agent-scope release / acquire pair) and runs the epilogue -- bitwise independent of which one that
- * is.  ws: 256-byte aligned, iggt_gemm_ws_bytes(M, N) bytes; its first 64 + 32 768 bytes must be ZERO before the first call (the
- * kernels leave them zero); word 0 is set to 1 if a bounded wait ever ran out (never on a healthy device).  One workspace per
- * stream.  ws == NULL: exactly iggt_gemm_bf16 / iggt_gemm_f16. */
-int iggt_gemm_bf16_ws(const void* A, long lda, const void* W, long ldw, int M, int N, int K,
-                      const float* bias, const float* gamma, const float* add_table,
-                      void* out, long ldo, int out_is_f32, int accumulate, int act,
-                      int rows_in, int rows_out, int row_off, void* ws, long ws_bytes, void* stream);
-int iggt_gemm_f16_ws(const void* A, long lda, const void* W, long ldw, int M, int N, int K,
-                     const float* bias, const float* gamma, const float* add_table,
-                     void* out, long ldo, int out_is_f32, int accumulate, int act,
-                     int rows_in, int rows_out, int row_off, void* ws, long ws_bytes, void* stream);
-long iggt_gemm_ws_bytes(int M, int N);
+/* (ABI v25's iggt_gemm_*_ws / iggt_gemm_ws_bytes -- a two-slice split-K behind a caller-owned workspace -- measured slower at
+ * every shape it applied to and were removed in ABI v26, round 6.) */
 
 /* softmax(scale * Q K^T) V, head dim 64, bf16 in/out, fp32 softmax; element (b,h,n,d) at
  * ptr + b*bs + n*rs + h*64 + d.  q_rows_per_wg: 0 (auto: tile chosen by shape) or an explicit code

@@ -32,5 +32,8 @@ class EmulatedShard:
             return out, (lambda: None)
         return out, stats.reshape(1, 32).repeat(self.world, 1), (lambda: None)
 
+    def agree_any(self, flags, device):
+        return [1 if f else 0 for f in flags]
+
     def all_gather_rows(self, x):
         return x.repeat(self.world, *([1] * (x.dim() - 1)))

@@ -46,3 +46,32 @@ def errors(got, ref):
     return (float(d.abs().max() / ref.abs().max().clamp_min(1e-30)),
             float(d.norm() / ref.norm().clamp_min(1e-30)),
             float(d.norm() / (ref - ref.mean()).norm().clamp_min(1e-30)))
+
+
+class FeatureTap:
+    """Captures the part branch's INPUTS during a forward: the SamProjector pyramid (part_adaptor -> res1..res4, NCHW-shaped
+    views) and the point head's fusion features (out2, out3, out4; NHWC maps) -- reference vggt.py:204-218 hands exactly
+    these to the part head.  `compare(g, meta)` returns errors() per fixture key (`adaptor_res*`, `point_feat_*`), sampled
+    like oracle/make_golden.py stored them (meta["feature_sample"] = (channel stride, row / column stride); whole maps in the
+    small fixtures)."""
+
+    def __init__(self, model):
+        self.cap = {}
+        self._h = [model.part_adaptor.register_forward_hook(lambda m, i, o: self.cap.__setitem__("ada", o[0])),
+                   model.point_head.register_forward_hook(lambda m, i, o: self.cap.__setitem__("pf", o[2]))]
+
+    def remove(self):
+        for h in self._h:
+            h.remove()
+
+    def compare(self, g, meta):
+        fsamp = meta.get("feature_sample")
+        cs, fs = (1, 1) if fsamp is None else (int(fsamp[0]), int(fsamp[1]))
+        res = {}
+        for k, v in self.cap.get("ada", {}).items():
+            if f"adaptor_{k}" in g:
+                res[f"adaptor_{k}"] = errors(v[:, ::cs, ::fs, ::fs], g[f"adaptor_{k}"])
+        for i, f in enumerate(self.cap.get("pf", ())):
+            if f"point_feat_{i}" in g:
+                res[f"point_feat_{i}"] = errors(f.permute(0, 3, 1, 2)[:, ::cs, ::fs, ::fs], g[f"point_feat_{i}"])
+        return res

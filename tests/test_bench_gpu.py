@@ -40,6 +40,14 @@ def test_bench_single_gpu_line():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["output_check"]["ok"]
     # round 5: the BASELINE checkpoint pays nothing for the precision rung
     assert d["precision_rung"]["escalated"] == 0 and d["precision_rung"]["blocks"] == 72 and d["precision_rung"]["policy"] == "auto"
+    # round 6: the whole model incl. the instance-feature branch at 532^2 rides in the default line
+    fm = d["full_model"]
+    assert fm["image_size"] == 532 and fm["views"] == 8 and fm["value"] > 0 and fm["part_branch_ms_per_forward"] > 0
+    assert fm["output_check"]["ok"] and fm["output_check"]["fixture"].endswith("full_s8_532_stress.pt")
+    assert fm["output_check"]["errors"]["part_feat"]["l2"] < 1e-3
+    kinds = " | ".join(e["kernel"] for e in fm["roofline_secondary"])
+    assert "window_attn_kernel (HAB" in kinds and "window_attn_kernel (OCAB" in kinds and "attn_f32_kernel<32>" in kinds
+    assert "part branch" in kinds and abs(fm["roofline"]["flops_per_launch"] - 4.0 * (8 * 1449) ** 2 * 1024) < 1.0
 
 
 def test_bench_on_a_heavy_tailed_checkpoint_reports_the_rung():

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from conftest import load_golden, report
-from helpers import build_gpu_model, errors
+from helpers import FeatureTap, build_gpu_model, errors
 
 pytestmark = pytest.mark.gpu
 
@@ -46,9 +46,12 @@ def _run(case, operands="f16"):
     images = weights.make_images(m["S"], m["H"], m["W"], seed=m["image_seed"], device="cuda")
     cap = {}
     h = model.aggregator.register_forward_hook(lambda mod, i, o: cap.__setitem__("tokens", o[0]))
+    tap = FeatureTap(model)
     pred = model(images)
     h.remove()
+    tap.remove()
     torch.cuda.synchronize()
+    _run.features = tap.compare(g, m)     # adaptor_res1..4 / point_feat_0..2 where the fixture holds them
     return g, m, pred, cap["tokens"]
 
 
@@ -70,6 +73,12 @@ def test_forward_matches_reference(case, operands):
         res["part_feat"] = errors(pred["part_feat"][:, :, :, ::ss, ::ss], g["part_feat"])
     else:
         assert "part_feat" not in pred
+    # the part branch's inputs (reference vggt.py:204-218): SamProjector pyramid and the point head's fusion features
+    res.update(_run.features)
+    if "part_feat" in g:
+        assert {"adaptor_res1", "adaptor_res2", "adaptor_res3", "adaptor_res4"} <= set(res), sorted(res)
+    if "point_feat_0" in g:
+        assert {"point_feat_0", "point_feat_1", "point_feat_2"} <= set(res), sorted(res)
     report(f"e2e/{case}" + ("" if operands == "f16" else "/bf16"), {k: dict(max=v[0], l2=v[1], l2_centered=v[2]) for k, v in res.items()})
     for k, v in pred.items():
         if torch.is_tensor(v):
@@ -87,6 +96,9 @@ def test_forward_matches_reference(case, operands):
     for k in ("depth", "depth_conf", "world_points", "world_points_conf", "part_feat", "pose_enc"):
         if k in res:
             assert res[k][1] < g_l2 and res[k][0] < g_max and res[k][2] < g_l2c, (k, res[k])
+    for k in res:
+        if k.startswith(("adaptor_", "point_feat_")):
+            assert res[k][1] < g_l2, (k, res[k])
 
 
 def test_dino_backbone_tokens():

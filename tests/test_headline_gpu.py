@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from conftest import load_golden, report
-from helpers import build_gpu_model, errors
+from helpers import FeatureTap, build_gpu_model, errors
 from test_kernels_gpu import _rand, _relerr
 
 pytestmark = pytest.mark.gpu
@@ -199,9 +199,11 @@ def _forward_vs_fixture(case, centered_gate=1e-3):
     cap = {}
     h = model.aggregator.register_forward_hook(lambda mod, i, o: cap.__setitem__("tokens", o[0]))
     hd = model.aggregator.patch_embed.register_forward_hook(lambda mod, i, o: None)
+    tap = FeatureTap(model)
     pred = model(images)
     h.remove()
     hd.remove()
+    tap.remove()
     torch.cuda.synchronize()
     ss, ts, cs = m["spatial_stride"], m["token_stride"], m.get("channel_stride", 1)
     res = {}
@@ -213,6 +215,7 @@ def _forward_vs_fixture(case, centered_gate=1e-3):
         res[k] = errors(pred[k][:, :, ::ss, ::ss], g[k])
     if "part_feat" in g:
         res["part_feat"] = errors(pred["part_feat"][:, :, :, ::ss, ::ss], g["part_feat"])
+        res.update(tap.compare(g, m))      # the part branch's inputs: SamProjector pyramid, point-head fusion features
     # whole-tensor statistics of the reference outputs pin what the strided samples skip
     stats = {}
     for k, st in g["stats"].items():
@@ -248,6 +251,24 @@ def test_forward_32_views_518_matches_reference():
 
 
 @pytest.mark.parametrize("case", ["full_s8_518_stress", "full_s32_518_stress"])
+def test_full_model_8_views_532_matches_reference():
+    """The WHOLE model -- geometry outputs AND `part_feat` (north_star's instance-feature maps) -- at BASELINE scale: 8 views @
+    532 x 532 (38 x 38 patch grid: the nearest size above 518 on which the reference's part head is defined, SURVEY appendix
+    D.2).  Fixture by the reference modules on CPU fp32 (oracle/make_golden.py full_s8_532_stress; the part head called one
+    frame at a time -- every operator in it is per frame -- so that the 17 GB score tensor of its dead `cross_attention_1`
+    exists for one frame only).  Also gated: the SamProjector pyramid (adaptor_res1..4) and the point head's fusion features
+    (point_feat_0..2) the part head consumes, as strided samples."""
+    res = _forward_vs_fixture("full_s8_532_stress")
+    assert {"part_feat", "adaptor_res1", "adaptor_res4", "point_feat_0", "point_feat_2"} <= set(res)
+
+
+def test_full_model_32_views_532_matches_reference():
+    """... and at BASELINE.json configs[2]'s view count: 32 views @ 532 x 532 incl. `part_feat` -- the configuration bench.py's
+    `full_model` leg times (N_global = 46 368)."""
+    res = _forward_vs_fixture("full_s32_532_stress")
+    assert "part_feat" in res and "adaptor_res1" in res
+
+
 def test_forward_bf16_operands_at_headline_sizes(case):
     """north_star's named operand type and the reference's own GPU arithmetic (autocast bf16, demo.py:190-195) at 8 and 32
     views @ 518^2: the bf16 gates of tests/test_e2e_gpu.py (that mode itself sits 7e-3 from fp32)."""
@@ -283,14 +304,38 @@ def test_forward_2_views_1036_matches_reference():
     per view (frame attention over 5 481 keys, N_global = 10 962), DINOv2 position table resampled 37 -> 74, DPT maps up to
     592^2 -> 1036^2.  Fixture: the reference modules on CPU fp32 at this size (oracle/make_golden.py full_s2_1036_stress),
     geometry outputs only -- the reference's part head needs 245 GB for its dead `cross_attention_1` at this size
-    (oracle/make_golden.py NO_PART); the product's part branch at 1036^2 is only checked for finiteness and shape here."""
-    from oracle import weights
-
+    (oracle/make_golden.py NO_PART).  `part_feat`, the SamProjector pyramid and the point head's fusion features are checked
+    against tests/golden/full_s2_1036_stress_part.pt, written by the CPU restatement after it matched the reference fixture of
+    this very input to < 5e-5 on every geometry output (oracle/make_golden_part_restate.py; the errors it measured are in the
+    fixture's meta)."""
     # north_star's bar (1e-3 relative) is met with margin (l2 <= 3.1e-4, max <= 7.8e-4 of the range); the stricter
     # mean-centred l2 (SURVEY fact 11) of depth_conf = 1 + exp(.) -- whose spread is 1/5.6 of its mean under the synthetic
     # weights -- measures 1.04e-3 at this size (9e-4 at 518^2), hence its own gate here
+    from oracle import weights
+
     _forward_vs_fixture("full_s2_1036_stress", centered_gate=1.5e-3)
-    model = build_gpu_model("stress", 0)
-    images = weights.make_images(1, 1036, 1036, seed=9, device="cuda")
-    part = model(images)["part_feat"]
-    assert part.shape == (1, 1, 8, 1036, 1036) and torch.isfinite(part).all()
+    g = load_golden("full_s2_1036_stress_part")
+    m = g["meta"]
+    assert max(m["restatement_vs_reference_fixture"].values()) < m["pin_tolerance"] <= 5e-5
+    model = build_gpu_model(m["mode"], m["weight_seed"])
+    images = weights.make_images(m["S"], m["H"], m["W"], seed=m["image_seed"], device="cuda")
+    tap = FeatureTap(model)
+    pred = model(images)
+    tap.remove()
+    torch.cuda.synchronize()
+    part = pred["part_feat"]
+    assert part.shape == (1, m["S"], 8, 1036, 1036) and torch.isfinite(part).all()
+    ss = m["spatial_stride"]
+    res = {"part_feat": errors(part[:, :, :, ::ss, ::ss], g["part_feat"])}
+    res.update(tap.compare(g, m))
+    st, v = g["stats"]["part_feat"], part.double()
+    dev = dict(mean=abs(float(v.mean()) - st["mean"]) / max(abs(st["mean"]), 1e-30),
+               abs_sum=abs(float(v.abs().sum()) - st["abs_sum"]) / st["abs_sum"], std=abs(float(v.std()) - st["std"]) / st["std"])
+    report("headline/full_s2_1036_stress_part", dict(errors={k: dict(max=e[0], l2=e[1], l2_centered=e[2]) for k, e in res.items()},
+                                                     stats_rel_dev=dev, oracle="restatement pinned to the reference fixture",
+                                                     pin=m["restatement_vs_reference_fixture"]))
+    assert {"part_feat", "adaptor_res1", "adaptor_res4", "point_feat_0", "point_feat_2"} <= set(res)
+    for k, e in res.items():
+        assert e[1] < 1e-3, (k, e)
+    assert res["part_feat"][0] < 1.5e-3 and res["part_feat"][2] < 1e-3, res["part_feat"]
+    assert dev["abs_sum"] < 1e-3 and dev["std"] < 2e-3, dev

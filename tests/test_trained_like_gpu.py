@@ -143,11 +143,12 @@ def test_heavy_tailed_well_conditioned_doses_meet_the_tolerance_on_the_x3_rung(c
     REPORTED (what single fp16 operands give at this dose, and what the rung costs)."""
     from iggt_official_amd import precision
 
+    prev = precision.escalation_policy()
     precision.set_escalation("off")
     try:
         res_off, att_off, _ = _run(case, warm=2)
     finally:
-        precision.set_escalation("auto")
+        precision.set_escalation(prev)
     res, att, _ = _run(case, warm=1)
     _report(case, res, att, dict(single_fp16_operands=dict(
         errors={k: dict(max=v[0], l2=v[1]) for k, v in res_off.items()}, forward_ms=att_off["forward_ms"],
@@ -171,6 +172,7 @@ def test_trained_like_literal_recipe_on_the_x3_rung(case):
     from iggt_official_amd import precision
 
     res, att, _ = _run(case, warm=1)
+    prev = precision.escalation_policy()
     precision.set_escalation("off")
     try:
         res_off, att_off, tok = _run(case)
@@ -189,7 +191,7 @@ def test_trained_like_literal_recipe_on_the_x3_rung(case):
                                                  tokens_23_l2_between_dispatch_modes=kernel_choice[1])
             assert kernel_choice[1] < 2.0 * res_off["tokens_23"][1] + 1e-3, (kernel_choice, res_off["tokens_23"])
     finally:
-        precision.set_escalation("auto")
+        precision.set_escalation(prev)
     _report(case, res, att, extra)
     assert att["escalated_blocks"] == 72, att
     assert res_off["tokens_23"][1] < 0.8, res_off["tokens_23"]
