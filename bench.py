@@ -548,7 +548,9 @@ def main():
     rung = {"blocks": rung["blocks"], "escalated": len(rung["x3"]), "ill_conditioned_by_own_figures": len(rung["own_verdict"]),
             "escalated_blocks": rung["x3"] if len(rung["x3"]) < rung["blocks"] else "all", "bf16_fallback": rung["bf16_fallback"],
             "min_participation_ratio": rung["min_participation_ratio"], "max_logit_rms": rung["max_logit_rms"],
-            "thresholds": {"participation_ratio_below": precision.ESC_PR_MIN, "logit_rms_above": precision.ESC_LOGIT_RMS_MAX},
+            "min_participation_ratio_untrimmed": rung["min_participation_ratio_untrimmed"],
+            "thresholds": {"participation_ratio_below": precision.ESC_PR_MIN, "channels_trimmed_per_1024": precision.ESC_PR_TRIM,
+                           "logit_rms_above": precision.ESC_LOGIT_RMS_MAX},
             "policy": precision.escalation()}
     if rung["escalated"]:
         was_graphs = model._graphs_on

@@ -72,6 +72,9 @@ _SIGNATURES = {
     "iggt_flash_attn_x3_f16_d64": [_c_void_p] * 7 + [_c_long] + [_c_int] * 4 + [_c_long] * 8 + [_c_void_p],
     "iggt_colmean_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "iggt_bias_correct_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
+    "iggt_comp_bias_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_int,
+                           _c_void_p, _c_long, _c_void_p],
+    "iggt_comp_bias_ws_bytes": [_c_int, _c_int],
     "iggt_head_tail_f32": [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int,
                            _c_int, _c_void_p],
     "iggt_window_attn_f32": [_c_void_p, _c_long, _c_int, _c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long,
@@ -134,7 +137,7 @@ _SIGNATURES = {
 }
 
 
-_LONG_RETURN = {"iggt_gemm_ws_bytes", "iggt_flash_attn_static_ws_bytes", "iggt_flash_attn_static_est_ws_bytes", "iggt_linear_f32_ws_bytes"}
+_LONG_RETURN = {"iggt_comp_bias_ws_bytes", "iggt_flash_attn_static_ws_bytes", "iggt_flash_attn_static_est_ws_bytes", "iggt_linear_f32_ws_bytes"}
 
 
 class HipExtensionError(RuntimeError):
@@ -487,6 +490,23 @@ def bias_correct(dw, mu, bias, out):
     rc = load().iggt_bias_correct_h16(dw.data_ptr(), dw.stride(0), dw.shape[0], dw.shape[1], mu.data_ptr(),
                                       _ptr(bias), out.data_ptr(), int(dw.dtype == torch.float16), _stream())
     _check(rc, "iggt_bias_correct_h16")
+    return out
+
+
+def comp_bias_ws_bytes(N, K):
+    return int(load().iggt_comp_bias_ws_bytes(int(N), int(K)))
+
+
+def comp_bias(x, dw, bias, out, ws, row_step=1):
+    """out = (bias or 0) + dw @ mean(x[::row_step]) in ONE launch (include/iggt_hip.h iggt_comp_bias_h16).  ws: uint8 workspace of
+    comp_bias_ws_bytes(N, K) bytes whose first word was zero when it was allocated (one per stream)."""
+    _dev(x, dw, bias, out, ws)
+    assert x.dtype in H16 and dw.dtype == x.dtype and x.stride(-1) == 1 and dw.stride(-1) == 1 and x.shape[1] == dw.shape[1]
+    assert out.dtype == torch.float32 and out.is_contiguous() and ws.dtype == torch.uint8 and ws.is_contiguous()
+    rc = load().iggt_comp_bias_h16(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], row_step, dw.data_ptr(), dw.stride(0),
+                                   dw.shape[0], _ptr(bias), out.data_ptr(), int(x.dtype == torch.float16), ws.data_ptr(),
+                                   ws.numel(), _stream())
+    _check(rc, "iggt_comp_bias_h16")
     return out
 
 

@@ -4,6 +4,17 @@
 
 namespace iggt_attn {
 
+// Workgroup barrier at the ISA level: exactly what __syncthreads() lowers to (release fence -- the compiler drains vmcnt / lgkmcnt
+// --, s_barrier, acquire fence), spelled out because the estimated-shift kernel (attention_v3.hip) lets the waves of one workgroup
+// choose between two copies of its tile loop: s_barrier releases a wave when EVERY wave of the workgroup has executed an s_barrier
+// -- the hardware counts arrivals, it does not compare program counters -- so waves in different copies synchronise correctly as
+// long as both copies execute the same number of barriers, which they do (one per macro tile + one in front of the loop).
+__device__ __forceinline__ void wg_barrier_counted() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 struct AttnParams {
     const bf16_t* q;
     const bf16_t* k;

@@ -493,10 +493,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
         }
     }
     // the tile loop, in two copies for the estimated-shift kernel: with and without the second block's shift correction (chosen
-    // per workgroup, below)
+    // per wave, below)
     auto tile_loop = [&](auto use_delta) {
         dma(mt0, mt0 & 1);
-        __syncthreads();  // vmcnt(0) + barrier: first macro tile resident
+        wg_barrier_counted();  // vmcnt(0) + barrier: first macro tile resident
         for (int mt = mt0; mt < NMT; ++mt) {
             if (mt + 1 < NMT) dma(mt + 1, (mt + 1) & 1);
     #pragma unroll
@@ -526,16 +526,21 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_v3_kernel(const AttnPar
                     }
                 }
             }
-            __syncthreads();  // everyone done with buffer mt&1; DMA of macro tile mt+1 landed
+            wg_barrier_counted();  // everyone done with buffer mt&1; DMA of macro tile mt+1 landed
         }
     };
     if constexpr (EST && QB == 2 && !EST_NODELTA) {
-        // per WORKGROUP: the correction only if some lane's two rows differ by more than IGGT_EST_DELTA_MAX bits (the pre-pass
-        // dealt the tile's 256 rows in shift order, so neighbours rarely do).  Each copy of the tile loop has its own
-        // __syncthreads(): the choice must be the same for all four waves, or waves of one workgroup would wait at DIFFERENT
-        // barrier instructions -- which the hardware's counted barriers tolerate and the HIP execution model does not define
-        // (round 4 / 5 chose per wave: ADVICE r4, r5).  __syncthreads_or is itself a barrier every wave reaches.
-        if (__syncthreads_or(fabsf(est_delta) > IGGT_EST_DELTA_MAX)) tile_loop(std::true_type{});
+        // per WAVE: the correction only if some lane's two rows differ by more than IGGT_EST_DELTA_MAX bits (the pre-pass dealt
+        // the tile's 256 rows in shift order, so neighbours rarely do).  Waves of one workgroup may therefore run DIFFERENT
+        // copies of the tile loop and meet at different barrier INSTRUCTIONS.  That is outside what HIP documents for
+        // __syncthreads(), so the loops do not use it: their barrier is the ISA-level wg_barrier_counted()
+        // (attention_common.h) -- s_barrier makes a wave wait until every wave of its workgroup has executed AN s_barrier; the
+        // hardware counts waves, not program counters, and both copies execute the same number per macro tile.  The two-
+        // workgroups-per-CU GEMM's ping-pong schedule (gemm_bf16_t256.hip) relies on the same property.  Measured alternatives
+        // (round 6, profiles/r06_attn_est_barrier_ab.txt): the choice made workgroup-uniform through __syncthreads_or costs
+        // +6 ... +8 % in the three adversarial regimes (any in-pair jump of a 256-row tile puts all four waves on the corrected
+        // loop); ONE loop around two barrier-free bodies allocates 256 VGPRs + 84 spilled.
+        if (__any(fabsf(est_delta) > IGGT_EST_DELTA_MAX)) tile_loop(std::true_type{});
         else tile_loop(std::false_type{});
     } else {
         tile_loop(std::false_type{});

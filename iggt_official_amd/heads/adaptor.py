@@ -42,8 +42,8 @@ class Projects(nn.Module):
             raise RuntimeError("Projects folds BatchNorm running statistics: call model.eval()")
         p0, p1, p2, p3 = self._packs()
         x1 = co.run(p0, x, act=1)                 # relu(bn(conv1x1 x))
-        y = co.run(p1, x1, act=1)                 # relu(bn(conv3x3))
-        y = co.run(p2, y, res=x1)                 # bn(conv3x3) + skip
+        y = co.run(p1, x1, act=1, prec=co.PART_PREC)     # relu(bn(conv3x3))
+        y = co.run(p2, y, res=x1, prec=co.PART_PREC)     # bn(conv3x3) + skip
         return co.run(p3, y)
 
 

@@ -79,18 +79,19 @@ class PartHead(DPTHead):
 
     def _fuse(self, features, point_feat):
         sc = self.scratch
-        r = [co.run(self._conv(("rn", i), getattr(sc, f"layer{i + 1}_rn")), features[i]) for i in range(4)]
-        out = sc.refinenet4.forward_nhwc(r[3], size=r[2].shape[1:3])
+        pr = co.PART_PREC
+        r = [co.run(self._conv(("rn", i), getattr(sc, f"layer{i + 1}_rn")), features[i], prec=pr) for i in range(4)]
+        out = sc.refinenet4.forward_nhwc(r[3], size=r[2].shape[1:3], prec=pr)
         if point_feat is not None:
             n, h, w, c = out.shape
             kv = point_feat[2].reshape(n, -1, c)
             out = self.cross_attention_2(out.reshape(n, h * w, c), kv, kv).reshape(n, h, w, c)
-        out = sc.refinenet3.forward_nhwc(out, r[2], size=r[1].shape[1:3])
-        out = sc.refinenet2.forward_nhwc(out, r[1], size=r[0].shape[1:3])
+        out = sc.refinenet3.forward_nhwc(out, r[2], size=r[1].shape[1:3], prec=pr)
+        out = sc.refinenet2.forward_nhwc(out, r[1], size=r[0].shape[1:3], prec=pr)
         if point_feat is not None:
             out = self.window_cross_attention(out, point_feat[0], point_feat[0])
-        out = sc.refinenet1.forward_nhwc(out, r[0])
-        return co.run(self._conv("oc1", sc.output_conv1), out)
+        out = sc.refinenet1.forward_nhwc(out, r[0], prec=pr)
+        return co.run(self._conv("oc1", sc.output_conv1), out, prec=pr)
 
     def _part_impl(self, maps, H, W, point_feat):
         gh, gw = H // self.patch_size, W // self.patch_size

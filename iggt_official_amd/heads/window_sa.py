@@ -233,9 +233,9 @@ class SwinSA(nn.Module):
         p0 = self._pk.get(0, (cab.weight, cab.bias), lambda: co.pack_conv2d(cab))
         p1 = self._pk.get(1, (cbu.weight, cbu.bias), lambda: co.pack_conv2d(cbu))
         p2 = self._pk.get(2, (cl.weight, cl.bias), lambda: co.pack_conv2d(cl))
-        y = co.run(p0, body, res=x)
-        y = co.run(p1, y, act=2)
-        return co.run(p2, y)
+        y = co.run(p0, body, res=x, prec=co.PART_PREC)
+        y = co.run(p1, y, act=2, prec=co.PART_PREC)
+        return co.run(p2, y, prec=co.PART_PREC)
 
     def forward(self, x):
         """x NHWC -> NHWC."""

@@ -257,6 +257,7 @@ class Aggregator(nn.Module):
                     own_verdict=[n for n, b in zip(names, order) if b.own_escalation()],
                     bf16_fallback=[n for n, p in zip(names, packs) if p is not None and p.get("bf16_fallback")],
                     min_participation_ratio=min(min(c["pr_norm1"], c["pr_norm2"]) for c in conds),
+                    min_participation_ratio_untrimmed=min(min(c["pr_norm1_raw"], c["pr_norm2_raw"]) for c in conds),
                     max_logit_rms=max(c["logit_rms"] for c in conds))
 
     def static_softmax_stats(self) -> dict:

@@ -92,7 +92,7 @@ class _Base(nn.Module, PyTorchModelHubMixin):
         key = (tuple(images.shape), precision.operand_name(), precision.static_softmax(),
                precision.mean_compensation_sites(), precision.gather_overlap(), precision.debug_saturation(), precision.static_guard(),
                precision.attn_estimated_shift(), precision.escalation(),
-               convops.PREC, convops.DPT_PREC,
+               convops.PREC, convops.DPT_PREC, convops.PART_PREC,
                None if shard is None else (shard.rank, shard.world, shard.kv_groups, shard.force))
 
         def fwd(static_in, ctl):

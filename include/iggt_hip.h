@@ -253,6 +253,14 @@ int iggt_dpt_tail_f32(const float* x, int N, int Hi, int Wi, int Ho, int Wo, con
 int iggt_colmean_h16(const void* x, long ld, int rows, int K, int row_step, int f16, float* mu, void* stream);
 int iggt_bias_correct_h16(const void* dw, long ldw, int N, int K, const float* mu, const float* bias, float* out,
                           int f16, void* stream);
+/* ABI v26 (round 6): both steps as ONE launch, out[n] = bias[n] + sum_k dw[n][k] * mean_rows(x)[k] with the same row sample.  One
+ * workgroup per 64 columns of K computes its slice of the mean and of the matrix-vector product; the last to finish (a ticket in
+ * the workspace) folds the slices in a fixed order -- the result does not depend on which one that is.  ws: 256-byte aligned,
+ * iggt_comp_bias_ws_bytes(N, K) bytes, its first 4 bytes ZERO before the first call (the kernel leaves them zero); one workspace
+ * per stream. */
+int iggt_comp_bias_h16(const void* x, long ld, int rows, int K, int row_step, const void* dw, long ldw, int N,
+                       const float* bias, float* out, int f16, void* ws, long ws_bytes, void* stream);
+long iggt_comp_bias_ws_bytes(int N, int K);
 
 /* Debug telemetry of the fp16 operand format: adds to *counter (device unsigned long long) the number of entries of the 16-bit
  * matrix x [rows][cols] (row stride ld) that are saturated (|x| = 65504, i.e. a clamped store) or not finite (f16 = 1), or

@@ -15,6 +15,6 @@ lines = [f"{'kernel':110s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min
 for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
     lines.append(f"{k[:110]:110s} {len(v):6d} {sum(v)/1e6:10.3f} {sum(v)/len(v)/1e3:10.2f} {min(v)/1e3:10.2f} {max(v)/1e3:10.2f} {100*sum(v)/max(tot,1):6.2f}")
 lines.append(f"TOTAL kernel time {tot/1e6:.3f} ms over {sum(len(v) for v in rows.values())} dispatches")
-open(sys.argv[1], 'w').write("\n".join(lines) + "\n")
+open(sys.argv[1], 'w').write("\n".join(lines) + "\n--- command output (tail) ---\n" + open('/tmp/prof_cmd.log').read()[-2500:])
 PY
 head -30 "$OUT"

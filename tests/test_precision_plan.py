@@ -29,6 +29,38 @@ def test_block_condition_figures():
     assert no_qk["logit_rms"] == 0.0
 
 
+def test_outlier_channels_do_not_trip_the_layernorm_criterion():
+    """Round 6: a handful of very large LayerNorm scales ("outlier dimensions" of trained ViTs) is not a heavy tail.  The
+    participation ratio over ALL channels cannot tell them apart (one gamma = 10 among 1 023 of ~1: 0.11 < the round-5 line of
+    0.15); the trimmed figure the rule uses can."""
+    one = torch.ones(1024)
+    one[5] = 10.0
+    assert precision.participation_ratio(one) < 0.15 < 0.9 < precision.participation_ratio(one, precision.ESC_PR_TRIM)
+    three = torch.ones(1024)
+    three[[5, 100, 700]] = torch.tensor([10.0, 20.0, 6.0])
+    c = precision.block_condition(one, three, torch.ones(64), torch.ones(64), 0.125)
+    assert c["pr_norm1_raw"] < 0.15 and c["pr_norm2_raw"] < 0.02 and min(c["pr_norm1"], c["pr_norm2"]) > 0.9
+    assert not precision.should_escalate(c)
+    # ... while a heavy tail over all channels still trips it: the synthetic doses (iggt_official_amd/synthetic.py)
+    from iggt_official_amd import synthetic
+
+    def trunk_min(mode):
+        vals = []
+        for blk in ("aggregator.patch_embed.blocks.3", "aggregator.frame_blocks.7", "aggregator.global_blocks.23"):
+            n1 = synthetic.make_tensor(blk + ".norm1.weight", (1024,), 0, mode)
+            n2 = synthetic.make_tensor(blk + ".norm2.weight", (1024,), 0, mode)
+            vals.append(precision.block_condition(n1, n2))
+        return vals
+
+    for mode, esc in (("stress", False), ("trained_like(qk=0.5,norm=0.5)", False), ("trained_like(qk=0,norm=1)", True),
+                      ("trained_like(qk=0,norm=0,tok=0,col=1,gauss=0,out=1,outmag=10)", False),
+                      ("trained_like(qk=0,norm=0,tok=0,col=1,gauss=0,out=3,outmag=8,outshare=1,massive=8)", False)):
+        conds = trunk_min(mode)
+        assert all(precision.should_escalate(c) == esc for c in conds), (mode, conds)
+    out = trunk_min("trained_like(qk=0,norm=0,tok=0,col=1,gauss=0,out=1,outmag=10)")
+    assert all(min(c["pr_norm1_raw"], c["pr_norm2_raw"]) < 0.15 for c in out)       # round 5 would have escalated all of them
+
+
 def test_plan_escalation_escalates_the_block_and_everything_upstream():
     blocks = _blocks(6)
     assert precision.plan_escalation(blocks) == [False] * 6 and all(b._x3_request is False for b in blocks)

@@ -257,3 +257,35 @@ def test_graph_replay_on_the_x3_rung():
         assert e[1] < 1e-3, e
     finally:
         model.enable_graphs(False)
+
+
+# Round 6 (review item 2 / ADVICE r5): OUTLIER CHANNELS.  Trained ViTs -- DINOv2 included -- carry a few LayerNorm scales that are
+# an order of magnitude above the rest ("outlier dimensions"), and massive activations on a handful of residual-stream channels.
+# That is not the heavy tail over ALL channels the doses above model, but the round-5 rule could not tell them apart: one
+# gamma = 10 among 1 023 of ~1 has a participation ratio of 0.11 < 0.15, so such a checkpoint would have put that block and
+# everything upstream on the x3 rung (2.6x the 32-view forward).  Fixtures by the reference modules, 8 views @ 518^2:
+#   tlG  one gamma = 10 in every norm1 / norm2 of the model (each LayerNorm its own channel), everything else as "stress"
+#   tlH  "DINOv2-like": the same 3 channels in every block carry gamma x 8 and rows x 8 of every mlp.fc2 (massive activations)
+# Both must meet 1e-3 on SINGLE fp16 operands, and the trimmed participation ratio (precision.block_condition) must leave every
+# block un-escalated; the rung is run as well and reported (what it would have cost, what it would have bought).
+@pytest.mark.parametrize("case", ["full_s8_518_tlG", "full_s8_518_tlH"])
+def test_outlier_channels_pass_on_single_operands_and_are_not_escalated(case):
+    from iggt_official_amd import precision
+
+    res, att, _ = _run(case, warm=2)
+    prev = precision.escalation_policy()
+    precision.set_escalation("all")
+    try:
+        res_x3, att_x3, _ = _run(case, warm=1)
+    finally:
+        precision.set_escalation(prev)
+    esc = build_gpu_model(load_golden(case)["meta"]["mode"], 0).aggregator.escalation_report()
+    _report(case, res, att, dict(min_participation_ratio_untrimmed=esc["min_participation_ratio_untrimmed"],
+                                 on_the_x3_rung=dict(errors={k: dict(max=v[0], l2=v[1]) for k, v in res_x3.items()},
+                                                     forward_ms=att_x3["forward_ms"])))
+    assert att["escalated_blocks"] == 0 and att["escalation"]["own_verdict"] == 0, att
+    assert esc["min_participation_ratio_untrimmed"] < 0.15 < precision.ESC_PR_MIN < esc["min_participation_ratio"]
+    for k, v in res.items():
+        assert v[1] < 1e-3, (case, k, v)
+        if not k.startswith("tokens"):
+            assert v[0] < 2e-3, (case, k, v)
