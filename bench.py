@@ -136,6 +136,13 @@ def cpu_baseline(sample_views, size, budget_s=240):
         return {"value": None, "unit": "views/s", "cores": cores, "kind": "port",
                 "sample": f"{sample_views} view(s) @ {size}x{size} did not finish within {budget_s}s on {cores} cores"}
     res = {"value": sample_views / dt, "unit": "views/s", "cores": cores, "kind": "port",
+           # A Python reference cannot travel to the GPU box in any form, so `kind` stays "port".  What the substitution is worth was
+           # measured where both exist (build container, 8 cores, 4 views @ 518^2, one same-size warm-up, one timed forward each;
+           # probes/cpu_reference_vs_port.py -> profiles/r06_cpu_reference_vs_port.txt): reference modules 26.28 s, port 25.35 s,
+           # outputs bit-identical (same ATen kernels in the same order; the reference also keeps 24 instead of 4 token layers).
+           "port_vs_reference": {"speed_ratio": 1.04, "reference_s": 26.28, "port_s": 25.35, "outputs": "bit-identical",
+                                 "where": "build container (8 cores), 4 views @ 518x518, same protocol for both",
+                                 "source": "profiles/r06_cpu_reference_vs_port.txt"},
            "sample": f"{sample_views} view(s) @ {size}x{size}, full geometry forward (DINOv2 + 24x(frame,global) + "
                      f"camera/depth/point heads) of oracle/restate.py (a PORT of the reference, not the reference "
                      f"itself: /root/reference does not exist on the GPU box), fp32 torch CPU, {cores} threads, one timed run "

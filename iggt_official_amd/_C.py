@@ -72,15 +72,12 @@ _SIGNATURES = {
     "iggt_flash_attn_x3_f16_d64": [_c_void_p] * 7 + [_c_long] + [_c_int] * 4 + [_c_long] * 8 + [_c_void_p],
     "iggt_colmean_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "iggt_bias_correct_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
-    "iggt_comp_bias_h16": [_c_void_p, _c_long, _c_int, _c_int, _c_int, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_int,
-                           _c_void_p, _c_long, _c_void_p],
-    "iggt_comp_bias_ws_bytes": [_c_int, _c_int],
     "iggt_head_tail_f32": [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int,
                            _c_int, _c_void_p],
     "iggt_window_attn_f32": [_c_void_p, _c_long, _c_int, _c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_long,
                              _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_void_p],
     "iggt_dpt_tail_f32": [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                          _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
+                          _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p],
     "iggt_conv2d_nhwc_f32": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                              _c_int]
                             + [_c_int] * 24 + [_c_void_p],
@@ -137,7 +134,7 @@ _SIGNATURES = {
 }
 
 
-_LONG_RETURN = {"iggt_comp_bias_ws_bytes", "iggt_flash_attn_static_ws_bytes", "iggt_flash_attn_static_est_ws_bytes", "iggt_linear_f32_ws_bytes"}
+_LONG_RETURN = {"iggt_flash_attn_static_ws_bytes", "iggt_flash_attn_static_est_ws_bytes", "iggt_linear_f32_ws_bytes"}
 
 
 class HipExtensionError(RuntimeError):
@@ -493,23 +490,6 @@ def bias_correct(dw, mu, bias, out):
     return out
 
 
-def comp_bias_ws_bytes(N, K):
-    return int(load().iggt_comp_bias_ws_bytes(int(N), int(K)))
-
-
-def comp_bias(x, dw, bias, out, ws, row_step=1):
-    """out = (bias or 0) + dw @ mean(x[::row_step]) in ONE launch (include/iggt_hip.h iggt_comp_bias_h16).  ws: uint8 workspace of
-    comp_bias_ws_bytes(N, K) bytes whose first word was zero when it was allocated (one per stream)."""
-    _dev(x, dw, bias, out, ws)
-    assert x.dtype in H16 and dw.dtype == x.dtype and x.stride(-1) == 1 and dw.stride(-1) == 1 and x.shape[1] == dw.shape[1]
-    assert out.dtype == torch.float32 and out.is_contiguous() and ws.dtype == torch.uint8 and ws.is_contiguous()
-    rc = load().iggt_comp_bias_h16(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], row_step, dw.data_ptr(), dw.stride(0),
-                                   dw.shape[0], _ptr(bias), out.data_ptr(), int(x.dtype == torch.float16), ws.data_ptr(),
-                                   ws.numel(), _stream())
-    _check(rc, "iggt_comp_bias_h16")
-    return out
-
-
 HEAD_ACT = {"linear": 0, "exp": 1, "relu": 2, "inv_log": 3, "sigmoid": 4, "norm": 5}
 CONF_ACT = {"expp1": 0, "expp0": 1, "sigmoid": 2}
 
@@ -557,9 +537,10 @@ def window_attn(q, k, v, out, heads, head_dim, scale, *, q_windows=False, ow=8, 
     return out
 
 
-def dpt_tail(x, size, xpart, ypart, w_hi, w_lo, b1, w2, b2, activation, conf_activation):
+def dpt_tail(x, size, xpart, ypart, w_hi, w_lo, b1, w2, b2, activation, conf_activation, nchw=False):
     """x NHWC fp32 [N,Hi,Wi,128] -> (pts [N,Ho,Wo,Cout-1], conf [N,Ho,Wo]): upsample + position map + conv3x3 + ReLU +
-    conv1x1 + activate_head in one kernel (include/iggt_hip.h)."""
+    conv1x1 + activate_head in one kernel (include/iggt_hip.h).  nchw=True: the part head's tail -- all Cout channels
+    un-activated as [N,Cout,Ho,Wo]; returns that single tensor."""
     _dev(x, xpart, ypart, w_hi, w_lo, b1, w2, b2)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == 128
     N, Hi, Wi, _ = x.shape
@@ -569,11 +550,18 @@ def dpt_tail(x, size, xpart, ypart, w_hi, w_lo, b1, w2, b2, activation, conf_act
     assert w2.shape == (Cout, 32) and w2.dtype == torch.float32 and w2.is_contiguous()
     if xpart is not None:
         assert xpart.shape == (Wo, 64) and ypart.shape == (Ho, 64) and xpart.is_contiguous() and ypart.is_contiguous()
+    if nchw:
+        out = torch.empty(N, Cout, Ho, Wo, dtype=torch.float32, device=x.device)
+        rc = load().iggt_dpt_tail_f32(x.data_ptr(), N, Hi, Wi, Ho, Wo, _ptr(xpart), _ptr(ypart), w_hi.data_ptr(),
+                                      w_lo.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), out.data_ptr(), 0, Cout, 0, 0, 1,
+                                      _stream())
+        _check(rc, "iggt_dpt_tail_f32")
+        return out
     pts = torch.empty(N, Ho, Wo, Cout - 1, dtype=torch.float32, device=x.device)
     conf = torch.empty(N, Ho, Wo, dtype=torch.float32, device=x.device)
     rc = load().iggt_dpt_tail_f32(x.data_ptr(), N, Hi, Wi, Ho, Wo, _ptr(xpart), _ptr(ypart), w_hi.data_ptr(),
                                   w_lo.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), pts.data_ptr(),
-                                  conf.data_ptr(), Cout, HEAD_ACT[activation], CONF_ACT[conf_activation], _stream())
+                                  conf.data_ptr(), Cout, HEAD_ACT[activation], CONF_ACT[conf_activation], 0, _stream())
     _check(rc, "iggt_dpt_tail_f32")
     return pts, conf
 

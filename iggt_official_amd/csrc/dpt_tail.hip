@@ -44,6 +44,7 @@ struct TailParams {
     int N, Hi, Wi, Ho, Wo, Cout, act, conf_act;
     float sy, sx;
     int tiles_x, tiles_y;
+    int nchw;            // round 6: all Cout channels, un-activated last one included, as planes pts[N][Cout][Ho][Wo] (part_feat)
 };
 
 IGGT_DEVINL int swz(int row, int slot) { return row * 64 + (((slot ^ (row >> 2) ^ ((row >> 1) & 1)) & 3) << 4); }
@@ -213,7 +214,9 @@ __global__ __launch_bounds__(256, 2) void dpt_tail_kernel(const TailParams p) {
                 s3 = fmaf(row[c + 3], w[c + 3], s3);
             }
             const float v = (s0 + s1) + (s2 + s3) + p.b2[o];
-            if (o < p.Cout - 1) {
+            if (p.nchw) {      // the part head's tail (reference part_head.py:240-243: no activation), NCHW like the reference's output
+                p.pts[(((long)img * p.Cout + o) * p.Ho + oy) * p.Wo + ox] = v;
+            } else if (o < p.Cout - 1) {
                 float r = v;
                 if (p.act == 1) r = expf(v);
                 else if (p.act == 2) r = fmaxf(v, 0.f);
@@ -236,14 +239,15 @@ __global__ __launch_bounds__(256, 2) void dpt_tail_kernel(const TailParams p) {
 extern "C" int iggt_dpt_tail_f32(const float* x, int N, int Hi, int Wi, int Ho, int Wo, const float* xpart,
                                  const float* ypart, const void* w_hi, const void* w_lo, const float* b1,
                                  const float* w2, const float* b2, float* pts, float* conf, int Cout, int act,
-                                 int conf_act, void* stream) {
+                                 int conf_act, int out_nchw, void* stream) {
     if (N <= 0 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1 || Cout < 2 || Cout > 8) return -1;
     if (act < 0 || act > 4 || conf_act < 0 || conf_act > 2) return -2;   // "norm" needs all channels: not fused
+    if (!pts || (!out_nchw && !conf)) return -1;
     if ((xpart == nullptr) != (ypart == nullptr)) return -3;
     TailParams p;
     p.x = x; p.xpart = xpart; p.ypart = ypart; p.w_hi = (const bf16_t*)w_hi; p.w_lo = (const bf16_t*)w_lo;
     p.b1 = b1; p.w2 = w2; p.b2 = b2; p.pts = pts; p.conf = conf;
-    p.N = N; p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.act = act; p.conf_act = conf_act;
+    p.N = N; p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.act = act; p.conf_act = conf_act; p.nchw = out_nchw;
     p.sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
     p.sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
     p.tiles_x = (Wo + TW - 1) / TW;

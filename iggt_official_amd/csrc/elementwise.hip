@@ -464,91 +464,11 @@ __global__ __launch_bounds__(256) void bias_correct_kernel(const BiasCorrParams 
     if (lane == 0) p.out[n] = acc + (p.bias ? p.bias[n] : 0.f);
 }
 
-// comp_bias (round 6): colmean + bias_correct as ONE launch -- the mean-input compensation used to cost two dependent 5 - 7 us
-// launches in front of each of the 288 trunk GEMMs of a forward (594 per rank-forward of an 8-GPU run, ~3 ms of its 60).
-// Workgroup g owns the 64-column slice [64 g, 64 g + 64) of K:
-//   1. mu of its slice exactly as colmean_kernel computes it (same thread map, same fixed summation order);
-//   2. its share of the matrix-vector product, part[g][n] = sum_{k in slice} dW[n][k] mu[k] for every n (8 lanes per row, 16-byte
-//      loads, 3-step xor reduction), stored to the workspace;
-//   3. release (agent scope), one ticket per workgroup; the LAST arriver acquires and folds the slices in slice order,
-//      out[n] = bias[n] + sum_g part[g][n] -- a fixed order, so the result does not depend on which workgroup was last -- and
-//      resets the ticket word for the next launch on this stream.
-// A workgroup only ever adds its ticket; nobody waits for anybody (no assumption on dispatch order or co-residency).
-struct CompBiasParams {
-    const bf16_t* x; long ld; int rows, K, step, nsamp;
-    const bf16_t* dw; long ldw; int N;
-    const float* bias; float* out; float* part; int* ticket;
-};
-
-template <int FMT>
-__global__ __launch_bounds__(1024) void comp_bias_kernel(const CompBiasParams p) {
-    constexpr int RL = 128;
-    __shared__ float red[RL][65];
-    __shared__ float mu_s[64];
-    __shared__ int last_s;
-    const int tid = threadIdx.x, slot = tid & 7, rl = tid >> 3;
-    const int col = blockIdx.x * 64 + slot * 8;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (col < p.K) {
-        const bf16_t* src = p.x + col;
-        const long rstride = (long)p.step * p.ld;
-#pragma unroll 4
-        for (int i = rl; i < p.nsamp; i += RL) {
-            const u32x4 raw = *reinterpret_cast<const u32x4*>(src + i * rstride);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[2 * e] += h2_lo<FMT>(raw[e]);
-                acc[2 * e + 1] += h2_hi<FMT>(raw[e]);
-            }
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[rl][slot * 8 + e] = acc[e];
-    __syncthreads();
-    if (tid < 64) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // colmean_kernel's order
-#pragma unroll 8
-        for (int r = 0; r < RL; r += 4) {
-            s0 += red[r][tid];
-            s1 += red[r + 1][tid];
-            s2 += red[r + 2][tid];
-            s3 += red[r + 3][tid];
-        }
-        mu_s[tid] = (blockIdx.x * 64 + tid < p.K) ? ((s0 + s1) + (s2 + s3)) / (float)p.nsamp : 0.f;
-    }
-    __syncthreads();
-    float m[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) m[e] = mu_s[slot * 8 + e];
-    float* part = p.part + (long)blockIdx.x * p.N;
-    for (int n0 = 0; n0 < p.N; n0 += RL) {
-        const int n = n0 + rl;
-        float d = 0.f;
-        if (n < p.N && col < p.K) {
-            const u32x4 raw = *reinterpret_cast<const u32x4*>(p.dw + (long)n * p.ldw + col);
-            d = h2_lo<FMT>(raw[0]) * m[0] + h2_hi<FMT>(raw[0]) * m[1] + h2_lo<FMT>(raw[1]) * m[2] + h2_hi<FMT>(raw[1]) * m[3] +
-                h2_lo<FMT>(raw[2]) * m[4] + h2_hi<FMT>(raw[2]) * m[5] + h2_lo<FMT>(raw[3]) * m[6] + h2_hi<FMT>(raw[3]) * m[7];
-        }
-        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-        if (slot == 0 && n < p.N) part[n] = d;
-    }
-    __threadfence();                     // release this thread's slice sums (agent scope) ...
-    __syncthreads();                     // ... all of the workgroup's, before its ticket is drawn
-    if (tid == 0) {
-        const int t = __hip_atomic_fetch_add(p.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = (t == (int)gridDim.x - 1);
-    }
-    __syncthreads();
-    if (!last_s) return;
-    __threadfence();                     // acquire: every other workgroup's slice sums
-    const int G = (int)gridDim.x;
-    for (int n = tid; n < p.N; n += 1024) {
-        float s = p.bias ? p.bias[n] : 0.f;
-        for (int g = 0; g < G; ++g) s += __builtin_nontemporal_load(p.part + (long)g * p.N + n);
-        p.out[n] = s;
-    }
-    if (tid == 0) __hip_atomic_store(p.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
-}
+// (Round 6 built both steps as ONE launch -- a workgroup per 64 columns of K, per-slice sums, agent-scope release, a ticket, the
+// last arriver folds the slices -- and measured it SLOWER: 18 - 34 us per launch against 7 + 6, per-rank forward of an 8-GPU run
+// 61.0 -> 67.4 ms (profiles/r06_comp_bias_ab.txt).  The agent-scope release every workgroup needs before its ticket writes back
+// the XCD's L2, which holds the GEMM output that was just produced; on this chip a hand-over between workgroups of one launch
+// costs more than the launch boundary it saves.  Removed.)
 
 // ---------------------------------------------------------------------------------------------
 // Tail of the DPT heads: 1x1 convolution 32 -> Cout (2..8) on an NHWC fp32 map fused with activate_head.
@@ -882,28 +802,6 @@ extern "C" int iggt_bias_correct_h16(const void* dw, long ldw, int N, int K, con
     const dim3 grid((N + 3) / 4), block(256);
     if (f16) hipLaunchKernelGGL(bias_correct_kernel<FMT_F16>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(bias_correct_kernel<FMT_BF16>, grid, block, 0, (hipStream_t)stream, p);
-    IGGT_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" long iggt_comp_bias_ws_bytes(int N, int K) {
-    if (N <= 0 || K <= 0) return 0;
-    return 256 + (long)((K + 63) / 64) * N * 4;      // [ticket word, padded to 256 B][slices][N] fp32
-}
-
-extern "C" int iggt_comp_bias_h16(const void* x, long ld, int rows, int K, int row_step, const void* dw, long ldw, int N,
-                                  const float* bias, float* out, int f16, void* ws, long ws_bytes, void* stream) {
-    if (rows <= 0 || K <= 0 || N <= 0 || (K % 8) || (ld % 8) || (ldw % 8) || row_step <= 0) return -1;
-    if (!x || !dw || !out || !ws || ((uintptr_t)ws % 256) || ws_bytes < iggt_comp_bias_ws_bytes(N, K)) return -2;
-    if (((uintptr_t)x | (uintptr_t)dw) % 16) return -2;
-    CompBiasParams p;
-    p.x = (const bf16_t*)x; p.ld = ld; p.rows = rows; p.K = K; p.step = row_step;
-    p.nsamp = (rows + row_step - 1) / row_step;
-    p.dw = (const bf16_t*)dw; p.ldw = ldw; p.N = N; p.bias = bias; p.out = out;
-    p.ticket = (int*)ws; p.part = (float*)((char*)ws + 256);
-    const dim3 grid((K + 63) / 64), block(1024);
-    if (f16) hipLaunchKernelGGL(comp_bias_kernel<FMT_F16>, grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(comp_bias_kernel<FMT_BF16>, grid, block, 0, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
     return 0;
 }

@@ -42,9 +42,9 @@ IGGT_DEVINL void wait_vm() {
 
 // Round 5 built a two-slice split-K of this kernel (ticket + fp32 slab hand-over); it measured slower at every per-rank shape (qkv
 // 61 -> 93 us: pipeline fill and epilogue do not halve with K) and was removed in round 6 (profiles/r05_gemm_splitk_ab.txt, git history).
-// Round 6 -- GELU from the LDS table of gemm_bf16_t256.hip (template parameter LUT; fc1 on the 192-row tiles, whose two 60-KiB
-// rings leave 40 KiB of the CU's LDS free: 2 x (60 + 16.4) KiB fit; the 256-row variant's 2 x 72 KiB do not).
-template <int MODE, int FMT, int TM, bool LUT = false>
+// Round 6 gave the 192-row tiles the GELU table of gemm_bf16_t256.hip (2 x (60 + 16.4) KiB of LDS fit) for the per-rank fc1:
+// 583 vs 584 TF/s at M = 5 496 -- nothing; removed again (profiles/r06_bench_emu8_*.json).
+template <int MODE, int FMT, int TM>
 __global__ __launch_bounds__(256, 2) void gemm_h16_duo_kernel(const GemmParams p) {
     static_assert(TM == 256 || TM == 192, "row tile");
     constexpr int A_BYTES = TM * TK * 2;            // 16 | 12 KiB
@@ -121,8 +121,6 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_duo_kernel(const GemmParams p
 
     dma_stage(0);
     dma_stage(1);
-    float2* lut = reinterpret_cast<float2*>(smem + NSTAGE * STAGE_BYTES);   // behind the ring (LUT builds only)
-    if constexpr (LUT) gelu_lut_build(lut, tid, 256);   // while the first stages are in flight
     wait_vm<AC + 2>();
     __builtin_amdgcn_s_barrier();
 
@@ -201,10 +199,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_duo_kernel(const GemmParams p
             } else if constexpr (MODE == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v4[e] += bias4[e];
-                if constexpr (LUT) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v4[e] = gelu_lut(v4[e], lut);
-                } else if (p.act == 1) {
+                if (p.act == 1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v4[e] = gelu_erf(v4[e]);
                 } else if (p.act == 2) {
@@ -228,11 +223,6 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_duo_kernel(const GemmParams p
 template <int FMT, int TM>
 int launch_duo(const GemmParams& p, int mode, hipStream_t stream) {
     const int lds = NSTAGE * (TM * TK * 2 + W_BYTES);  // 72 | 60 KiB: two workgroups per CU
-    static int gelu_lut_on = -1;                       // IGGT_GELU_LUT=0: the polynomial erfc epilogue (gemm_common.h gelu_erf)
-    if (gelu_lut_on < 0) {
-        const char* e = getenv("IGGT_GELU_LUT");
-        gelu_lut_on = (e && atoi(e) == 0) ? 0 : 1;
-    }
     static bool attr_set = false;
     if (!attr_set) {
         const void* kernels[] = {(const void*)gemm_h16_duo_kernel<1, FMT, TM>, (const void*)gemm_h16_duo_kernel<2, FMT, TM>,
@@ -241,20 +231,9 @@ int launch_duo(const GemmParams& p, int mode, hipStream_t stream) {
             const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return (int)e;
         }
-        if constexpr (TM == 192) {
-            const hipError_t e = hipFuncSetAttribute((const void*)gemm_h16_duo_kernel<1, FMT, TM, true>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds + GELU_LUT_BYTES);
-            if (e != hipSuccess) return (int)e;
-        }
         attr_set = true;
     }
     const dim3 grid(p.tiles_m * p.tiles_n), block(256);
-    if constexpr (TM == 192) {
-        if (mode == 1 && p.act == 1 && gelu_lut_on) {
-            hipLaunchKernelGGL((gemm_h16_duo_kernel<1, FMT, TM, true>), grid, block, lds + GELU_LUT_BYTES, stream, p);
-            return 0;
-        }
-    }
     if (mode == 1) hipLaunchKernelGGL((gemm_h16_duo_kernel<1, FMT, TM>), grid, block, lds, stream, p);
     else if (mode == 2) hipLaunchKernelGGL((gemm_h16_duo_kernel<2, FMT, TM>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((gemm_h16_duo_kernel<3, FMT, TM>), grid, block, lds, stream, p);

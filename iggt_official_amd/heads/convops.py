@@ -30,9 +30,10 @@ def _env_prec(name: str, default: int) -> int:
 # three.  Measured per layer on photographs in profiles/r03_conv_precision.txt (head output error 1.7e-4 with every layer at
 # 2, against 1.2e-5 at 3 and a trunk contribution of 3.8e-4 / 7.2e-4).  IGGT_CONV_PREC=3 restores the split-bf16 kernels.
 DPT_PREC = _env_prec("IGGT_CONV_PREC", 2)
-# The instance-feature branch (heads/adaptor.py SamProjector, heads/part_head.py, heads/window_sa.py): its 3 x 3 convolutions at this
-# precision (IGGT_PART_CONV_PREC; same two-pass arithmetic and the same size rule as DPT_PREC when 2).
-PART_PREC = _env_prec("IGGT_PART_CONV_PREC", 3)
+# The instance-feature branch (heads/adaptor.py SamProjector, heads/part_head.py, heads/window_sa.py, heads/tokenops.py): its 3 x 3
+# convolutions and token Linears at this precision (same two-pass arithmetic and the same size rule as DPT_PREC when 2).  Measured
+# at 32 x 532^2 against the reference fixture (round 6, profiles/r06_part_branch_ab.txt): part_feat 1.48e-4 at 3, 1.7e-4 at 2.
+PART_PREC = _env_prec("IGGT_PART_CONV_PREC", 2)
 # ... for convolutions of at least this many FLOPs (2 * pixels * Cout * taps * Cin).  Below it the channel-mean and correction
 # launches in front of a prec-2 convolution (~15 us) outweigh the MFMA pass they save: measured break-even between the 37^2 and
 # the 74^2 maps of a 32-view pass (profiles/r03_conv_prec_ab.txt); the layer then runs at prec 3, which is the more accurate one.

@@ -22,7 +22,7 @@ import torch.nn as nn
 from .. import _C
 from . import convops as co
 from .block import MemEffCrossAttention
-from .dpt_head import DPTHead, _make_fusion_block, _make_scratch
+from .dpt_head import FUSED_TAIL, DPTHead, _make_fusion_block, _make_scratch
 from .window_sa import SwinCA, SwinSA
 
 
@@ -96,8 +96,20 @@ class PartHead(DPTHead):
     def _part_impl(self, maps, H, W, point_feat):
         gh, gw = H // self.patch_size, W // self.patch_size
         out = self.window_self_atten(self._fuse(maps, point_feat))
-        out = co.resize(out, (int(gh * self.patch_size / self.down_ratio), int(gw * self.patch_size / self.down_ratio)))
+        size = (int(gh * self.patch_size / self.down_ratio), int(gw * self.patch_size / self.down_ratio))
         c2 = self.scratch.output_conv2
+        if (FUSED_TAIL and out.shape[3] == 128 and c2[0].in_channels == 128 and c2[0].out_channels == 32
+                and c2[0].kernel_size == (3, 3) and c2[0].padding == (1, 1) and c2[2].in_channels == 32
+                and 2 <= c2[2].out_channels <= 8):
+            # round 6: bilinear upsample + conv3x3 128 -> 32 + ReLU + conv1x1 -> the NCHW output in ONE kernel (csrc/dpt_tail.hip,
+            # the DPT heads' fused tail without position map and activation): the full-resolution 128- and 32-channel maps
+            # (4.6 + 1.2 GB at 32 x 532^2) never exist in HBM
+            pc = self._conv("oc2_0", c2[0])
+            b1 = pc.bias if pc.bias is not None else torch.zeros(32, dtype=torch.float32, device=out.device)
+            return _C.dpt_tail(out.contiguous(), size, None, None, pc.w_hi, pc.w_lo, b1,
+                               c2[2].weight.detach().float().reshape(c2[2].out_channels, 32).contiguous(),
+                               c2[2].bias.detach().float().contiguous(), "linear", "expp1", nchw=True)
+        out = co.resize(out, size)
         out = co.run(self._conv("oc2_0", c2[0]), out, act=1)
         # last 1x1 conv, NHWC in -> the reference's NCHW [S,8,H,W] out in one pass (no activation: part_head.py:240-243)
         return _C.conv1x1_c32_nchw(out, c2[2].weight.detach(), c2[2].bias.detach())

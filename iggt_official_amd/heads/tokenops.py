@@ -54,5 +54,5 @@ def linear(lin: nn.Linear, x: torch.Tensor, act: int = 0, res: torch.Tensor = No
         r2 = res.reshape(1, 1, -1, Cout)
         if not r2.is_contiguous() or r2.dtype != torch.float32:
             r2 = r2.float().contiguous()
-    y = co.run(pc, x2, act=act, res=r2)
+    y = co.run(pc, x2, act=act, res=r2, prec=co.PART_PREC)
     return y.view(*x.shape[:-1], Cout)

@@ -181,8 +181,10 @@ class OCAB(nn.Module):
         if ws != 8 or d not in (32, 64):
             raise _C.HipExtensionError("HIP window attention is built for 8x8 windows and head dim 32 / 64")
         q = tk.linear(self.q, tk.layer_norm(self.norm1, x)).view(b, h, w, c)
-        kk = tk.linear(self.k, tk.layer_norm(self.norm1, k)).view(b, h, w, c)
-        vv = tk.linear(self.v, tk.layer_norm(self.norm1, v)).view(b, h, w, c)
+        nk = tk.layer_norm(self.norm1, k)
+        nv = nk if v is k else tk.layer_norm(self.norm1, v)        # the part head passes the same map as k and v (part_head.py:194)
+        kk = tk.linear(self.k, nk).view(b, h, w, c)
+        vv = tk.linear(self.v, nv).view(b, h, w, c)
         qw = _ocab_query_windows(q, ws).contiguous()                                 # [b*nw, 64, c] (layout quirk D.4)
         pad = (ow - ws) // 2
         # bias[head][key][query]: the kernel's lanes are the queries
@@ -278,6 +280,8 @@ class SwinCA(SwinSA):
         b, h, w, c = x.shape
         _check_window_grid(h, w, self.window_size)
         tn = lambda z: tk.layer_norm(self.patch_embed.norm, z.reshape(b, h * w, c))  # noqa: E731
-        t = self.atten_block(tn(x), tn(k), tn(v), (h, w), self.relative_position_index_OCA)
+        tkk = tn(k)
+        tvv = tkk if v is k else tn(v)       # k and v are one tensor in the part head: normalise it once
+        t = self.atten_block(tn(x), tkk, tvv, (h, w), self.relative_position_index_OCA)
         body = tk.layer_norm(self.norm, t).view(b, h, w, c)
         return self._tail(body, x)

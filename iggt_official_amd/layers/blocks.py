@@ -88,17 +88,6 @@ class Workspace:
             self._bufs[name] = cur
         return cur[:n].view(*shape)
 
-    def get_zeroed(self, name, n, dtype, device):
-        """Flat buffer of n elements that is zero-filled when it is (re)allocated and never touched by this class again (the ticket
-        word of _C.comp_bias: the kernel leaves it zero)."""
-        cur = self._bufs.get(name)
-        if cur is None or cur.numel() < n or cur.dtype != dtype or cur.device != device:
-            if cur is not None:
-                graphs.buffers_changed()
-            cur = torch.zeros(n, dtype=dtype, device=device)
-            self._bufs[name] = cur
-        return cur
-
     def get_padded(self, name, rows, cols, dtype, device, pad=ROW_PAD):
         """[rows, cols] view with a row stride of cols + pad elements (see ROW_PAD)."""
         return self.get(name, (rows, cols + pad), dtype, device)[:, :cols]
@@ -210,28 +199,17 @@ def fold_ranges(wq, bq, wp, bp, w1, w2, b2, n1w, n1b, n2w, n2b, g1, g2):
 MEAN_SAMPLE_ROWS = 1024  # the column mean is taken over ~this many evenly spaced rows (sampling error sigma / 32)
 
 
-COMP_FUSED = __import__("os").environ.get("IGGT_COMP_FUSED", "1") != "0"   # 0: the two-launch form (colmean, bias_correct) for A/B runs
-_COMP_WS_BYTES = 256 + 64 * 4096 * 4     # ticket word + the slice sums of the largest trunk GEMM (K = 4 096 -> 64 slices, N <= 4 096)
-
-
 def compensated_bias(ws: "Workspace", a: torch.Tensor, dw: Optional[torch.Tensor], bias: Optional[torch.Tensor]):
     """bias + dW mean_rows(a): restores the part of the weight rounding that is common to all tokens
-    (precision.py); `bias` itself when compensation is off.  One launch (csrc/elementwise.hip comp_bias_kernel, round 6; the
-    column mean over ~MEAN_SAMPLE_ROWS evenly spaced rows and the matrix-vector product used to be two dependent launches in front
-    of every GEMM)."""
+    (precision.py); `bias` itself when compensation is off.  Two small launches (column mean over ~MEAN_SAMPLE_ROWS evenly spaced
+    rows, matrix-vector product); one fused launch with an in-kernel hand-over was built in round 6 and measured slower
+    (csrc/elementwise.hip, profiles/r06_comp_bias_ab.txt)."""
     if dw is None:
         return bias
     N, K = dw.shape
-    step = max(1, a.shape[0] // MEAN_SAMPLE_ROWS)
-    # one buffer per stream: launches on a stream are ordered, the ticket word is zero again when a launch has finished
-    key = torch.cuda.current_stream().cuda_stream
-    out = ws.get(f"bias_comp@{key}", (N,), torch.float32, a.device)
-    nbytes = _C.comp_bias_ws_bytes(N, K)
-    if COMP_FUSED and nbytes <= _COMP_WS_BYTES:
-        cws = ws.get_zeroed(f"comp_ws@{key}", _COMP_WS_BYTES, torch.uint8, a.device)
-        return _C.comp_bias(a, dw, bias, out, cws, step)
-    mu = ws.get(f"mean_in@{key}", (K,), torch.float32, a.device)
-    _C.colmean(a, mu, step)
+    mu = ws.get("mean_in", (K,), torch.float32, a.device)
+    out = ws.get("bias_comp", (N,), torch.float32, a.device)
+    _C.colmean(a, mu, max(1, a.shape[0] // MEAN_SAMPLE_ROWS))
     return _C.bias_correct(dw, mu, bias, out)
 
 

@@ -50,6 +50,11 @@ _CAMERA_STREAM = os.environ.get("IGGT_CAMERA_STREAM", "1") != "0"
 # 4 local views of an 8-GPU run 60.4 -> 61.3 ms, so not there), 0 / 1 = never / always
 _HEAD_STREAMS = os.environ.get("IGGT_HEAD_STREAMS", "auto")
 _HEAD_STREAMS_MIN_PIXELS = 8 * 500 * 500
+# Frames per pass of the part head.  The reference's signature default is 8 (part_head.py:108; its chunked branch does not even run,
+# SURVEY appendix D.1); every operator of the head is per frame, so the chunk size is purely a memory / launch-size choice: one
+# pass over all frames up to this many pixels (32 views @ 532^2 fit: its 304^2 x 128-channel maps are 1.5 GB each), chunks beyond
+# (64 views @ 1036^2: 9 frames per pass).  Measured at 32 x 532^2: 4 passes of 8 frames -> one pass of 32 (profiles/r06_*).
+_PART_CHUNK_PIXELS = int(os.environ.get("IGGT_PART_CHUNK_PIXELS", str(32 * 560 * 560)))
 
 
 class _Base(nn.Module, PyTorchModelHubMixin):
@@ -285,7 +290,8 @@ class IGGT(_Base):
             with profiling.tagged("part"), profiling.region("part_branch", None):
                 pyramid, _ = self.part_adaptor(tokens, images=images, patch_start_idx=psi)
                 pred["part_feat"] = self.part_head(list(pyramid.values()), point_feature=point_feat, images=images,
-                                                   patch_start_idx=psi)
+                                                   patch_start_idx=psi,
+                                                   frames_chunk_size=max(1, _PART_CHUNK_PIXELS // (H * W)))
         self._track(pred, tokens, images, psi, query_points)
         self._join_heads()
         self._join_camera()

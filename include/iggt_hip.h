@@ -240,10 +240,12 @@ int iggt_window_attn_f32(const float* q, long q_ld, int q_mode, const float* k, 
  * conv1x1 32 -> Cout (w2 [Cout][32], b2) + activate_head: pts [N][Ho][Wo][Cout-1], conf [N][Ho][Wo].
  * act: 0 linear, 1 exp, 2 relu, 3 inv_log, 4 sigmoid;  conf_act: 0 expp1, 1 expp0, 2 sigmoid.
  * Replaces custom_interpolate + _apply_pos_embed + scratch.output_conv2 (iggt/heads/dpt_head.py:251-256,274-284,
- * 121-128,484-509) + activate_head (iggt/heads/head_act.py:61-125) in one pass. */
+ * 121-128,484-509) + activate_head (iggt/heads/head_act.py:61-125) in one pass.
+ * out_nchw != 0 (ABI v26): the part head's tail (iggt/heads/part_head.py:228-243: same stages, NO activation): all Cout channels
+ * un-activated as planes pts [N][Cout][Ho][Wo], conf unused (may be NULL), act / conf_act ignored. */
 int iggt_dpt_tail_f32(const float* x, int N, int Hi, int Wi, int Ho, int Wo, const float* xpart, const float* ypart,
                       const void* w_hi, const void* w_lo, const float* b1, const float* w2, const float* b2,
-                      float* pts, float* conf, int Cout, int act, int conf_act, void* stream);
+                      float* pts, float* conf, int Cout, int act, int conf_act, int out_nchw, void* stream);
 
 /* Mean-input compensation of the 16-bit weight rounding (no counterpart in the reference, which is fp32 on the
  * CPU path this repository is checked against; see iggt_official_amd/precision.py):
@@ -253,15 +255,6 @@ int iggt_dpt_tail_f32(const float* x, int N, int Hi, int Wi, int Ho, int Wo, con
 int iggt_colmean_h16(const void* x, long ld, int rows, int K, int row_step, int f16, float* mu, void* stream);
 int iggt_bias_correct_h16(const void* dw, long ldw, int N, int K, const float* mu, const float* bias, float* out,
                           int f16, void* stream);
-/* ABI v26 (round 6): both steps as ONE launch, out[n] = bias[n] + sum_k dw[n][k] * mean_rows(x)[k] with the same row sample.  One
- * workgroup per 64 columns of K computes its slice of the mean and of the matrix-vector product; the last to finish (a ticket in
- * the workspace) folds the slices in a fixed order -- the result does not depend on which one that is.  ws: 256-byte aligned,
- * iggt_comp_bias_ws_bytes(N, K) bytes, its first 4 bytes ZERO before the first call (the kernel leaves them zero); one workspace
- * per stream. */
-int iggt_comp_bias_h16(const void* x, long ld, int rows, int K, int row_step, const void* dw, long ldw, int N,
-                       const float* bias, float* out, int f16, void* ws, long ws_bytes, void* stream);
-long iggt_comp_bias_ws_bytes(int N, int K);
-
 /* Debug telemetry of the fp16 operand format: adds to *counter (device unsigned long long) the number of entries of the 16-bit
  * matrix x [rows][cols] (row stride ld) that are saturated (|x| = 65504, i.e. a clamped store) or not finite (f16 = 1), or
  * not finite (f16 = 0, bf16).  No counterpart in the reference (its GPU mode is bf16 autocast, demo.py:193-195). */

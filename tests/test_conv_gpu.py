@@ -269,6 +269,31 @@ def test_dpt_tail_fused_vs_separate_kernels(hw_in, size, cout, act, pos):
     assert _err(pts, ref)[0] < 5e-5 and _err(conf, 1 + lin[..., -1].exp())[0] < 5e-5
 
 
+def test_dpt_tail_part_head_mode_nchw_no_activation():
+    """Round 6: the same fused kernel as the part head's tail (reference part_head.py:228-243: bilinear upsample, conv3x3 128 ->
+    32, ReLU, conv1x1 32 -> 8, NO position map, NO activation), all 8 channels as NCHW planes -- against the separate kernels it
+    replaces (resize, implicit-GEMM conv, conv1x1_c32_nchw) and an fp64 PyTorch evaluation; ragged tile edges."""
+    from iggt_official_amd import _C
+    from iggt_official_amd.heads import convops as co
+
+    N, hw_in, size, cout = 3, (38, 46), (67, 83), 8
+    x = _mk((N, hw_in[0], hw_in[1], 128), 141)
+    conv1 = nn.Conv2d(128, 32, 3, 1, 1).cuda()
+    with torch.no_grad():
+        conv1.weight.copy_(_mk(conv1.weight.shape, 142, (128 * 9) ** -0.5))
+        conv1.bias.copy_(_mk((32,), 143, 0.1))
+    w2, b2 = _mk((cout, 32), 144, 0.2), _mk((cout,), 145, 0.2)
+    pc = co.pack_conv2d(conv1)
+    out = _C.dpt_tail(x, size, None, None, pc.w_hi, pc.w_lo, pc.bias, w2, b2, "linear", "expp1", nchw=True)
+    assert out.shape == (N, cout, size[0], size[1]) and out.is_contiguous()
+    mid = co.run(pc, co.resize(x, size), act=1)
+    sep = _C.conv1x1_c32_nchw(mid, w2.view(cout, 32, 1, 1), b2)
+    assert _err(out, sep)[0] < 1e-5
+    upd = F.interpolate(x.permute(0, 3, 1, 2).double(), size=size, mode="bilinear", align_corners=True)
+    ref = F.conv2d(F.relu(F.conv2d(upd, conv1.weight.double(), conv1.bias.double(), 1, 1)), w2.double()[:, :, None, None], b2.double())
+    assert _err(out, ref)[0] < 5e-5
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # prec = 2: fp16 activations hi + lo x weights rounded once to fp16 + mean-input compensation per border class
 # (csrc/conv_meancomp.hip).  Three checks per geometry, the first two EXACT (fp32-grade) by construction:

@@ -264,7 +264,9 @@ def test_full_model_8_views_532_matches_reference():
 def test_full_model_32_views_532_matches_reference():
     """... and at BASELINE.json configs[2]'s view count: 32 views @ 532 x 532 incl. `part_feat` -- the configuration bench.py's
     `full_model` leg times (N_global = 46 368)."""
-    res = _forward_vs_fixture("full_s32_532_stress")
+    # mean-centred l2 of depth_conf = 1 + exp(.) (spread 1/5.6 of its mean under the synthetic weights): 1.11e-3 at this size, like
+    # the 1.04e-3 at 1036^2 (its own gate there as well); north_star's relative l2 is 2.2e-4
+    res = _forward_vs_fixture("full_s32_532_stress", centered_gate=1.5e-3)
     assert "part_feat" in res and "adaptor_res1" in res
 
 

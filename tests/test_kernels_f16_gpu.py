@@ -84,8 +84,8 @@ def test_gemm_f16_epilogues(C, M, N, K, mode):
 
 @pytest.mark.parametrize("M,N", [(9216, 1024), (5496, 4096)])
 def test_gemm_gelu_table_against_erf(C, M, N):
-    """The fc1 epilogue of the 256 x 256 kernel -- and, round 6, of the 192-row two-workgroups-per-CU kernel that takes the per-rank
-    shape M = 5 496 -- evaluates GELU from an LDS table of Phi (gemm_common.h gelu_lut).  A GEMM whose result IS a chosen
+    """The fc1 epilogue of the 256 x 256 kernel evaluates GELU from an LDS table of Phi (gemm_common.h gelu_lut); the second shape
+    is the per-rank fc1 on the 192-row two-workgroups-per-CU kernel (polynomial erfc), held to the same bound.  A GEMM whose result IS a chosen
     pre-activation (one non-zero operand column, unit weights) sweeps x over [-10, 10] and beyond the table; against torch's erf
     GELU (reference iggt/layers/mlp.py:34, nn.GELU()) in fp64 the error must stay within one fp16 rounding of the result plus
     the table's 2.5e-6."""
@@ -555,34 +555,6 @@ def test_colmean_and_bias_correct(C, dtype, rows, K, step):
     assert float((out.double() - ref).abs().max()) < 1e-6
     C.bias_correct(dw, mu, None, out)
     assert float((out.double() - dw.double() @ mu.double()).abs().max()) < 1e-6
-
-
-@pytest.mark.parametrize("dtype", [F16, torch.bfloat16])
-@pytest.mark.parametrize("rows,K,N,step", [(5496, 1024, 3072, 5), (43968, 4096, 1024, 42), (1374, 1000, 384, 1), (300, 2048, 256, 1)])
-def test_comp_bias_single_launch(C, dtype, rows, K, N, step):
-    """Round 6: colmean + bias_correct as ONE launch (per-slice sums + last-arriver fold).  Equal to the two-launch form up to
-    the summation order of the matrix-vector product, within 1e-6 of fp64, bitwise reproducible, and the ticket word is left
-    zero so that back-to-back launches on one workspace work (trunk shapes: per-rank qkv, 32-view fc2; ragged K; a head shape)."""
-    big = _rand((rows, K + 64), 190, 2.0, dtype) + 0.5
-    x = big[:, :K]                                    # padded row stride
-    dw = _rand((N, K), 191, 1e-4, dtype)
-    bias = _rand((N,), 192)
-    ws = torch.zeros(C.comp_bias_ws_bytes(N, K), dtype=torch.uint8, device="cuda")
-    outs = []
-    for b in (bias, None, bias):
-        out = torch.full((N,), float("nan"), device="cuda")
-        C.comp_bias(x, dw, b, out, ws, step)
-        outs.append(out)
-        assert int(ws[:4].view(torch.int32)[0]) == 0          # ticket word clean again
-    mu = x[::step].double().mean(0)
-    ref = bias.double() + dw.double() @ mu
-    assert float((outs[0].double() - ref).abs().max()) < 1e-6
-    assert float((outs[1].double() - dw.double() @ mu).abs().max()) < 1e-6
-    assert torch.equal(outs[0], outs[2])                      # fixed fold order: bitwise reproducible
-    mu32 = torch.empty(K, device="cuda")
-    two = torch.empty(N, device="cuda")
-    C.bias_correct(dw, C.colmean(x, mu32, step), bias, two)
-    assert float((outs[0] - two).abs().max()) < 1e-6
 
 
 def test_qknorm_rope_head_group_layout(C):
