@@ -353,8 +353,9 @@ def _full_model_leg(model, dev, S, mode, steps):
     for kind in sorted({r[1][0] for r in recs["window_attn"]}):
         rs = [r for r in recs["window_attn"] if r[1][0] == kind]
         e = fam(rs, 157.3)
-        e.update(kernel=f"window_attn_kernel ({kind}; fp32 on the vector ALU: one wave per (window, head), lane = query)",
-                 bound="valu-fp32", peak_note="fp32 vector / matrix peak of the guide (157.3 TFLOP/s); the stage is < 0.2 TFLOP")
+        e.update(kernel=f"window_attn_kernel ({kind}; exact fp32 MFMA v_mfma_f32_32x32x2_f32, two waves per (window, head), K / V tiles in LDS)",
+                 bound="mfma-fp32", peak_note="fp32 matrix peak of the guide (157.3 TFLOP/s); the stage is < 0.2 TFLOP and reads "
+                                              "~1.5 (HAB) / ~0.8 (OCAB) GB per 32-view pass")
         sec.append(e)
     if recs["cross_attn"]:
         e = fam(recs["cross_attn"], 157.3)

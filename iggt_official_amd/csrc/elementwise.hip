@@ -541,10 +541,9 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const TailParams p) {
 //   OCAB (window_sa.py:229-319): 8x8 query windows, 12x12 overlapping key/value windows (stride 8, zero padding 2:
 //        out-of-image keys are ZERO VECTORS that still take part in the softmax with score = bias, as nn.Unfold
 //        pads with zeros), learned relative-position bias.
-// One wave per (window, head), lane = query token: the query row (D floats) and the output accumulator live in
-// registers; key / value rows are wave-uniform addresses (scalar loads), online softmax per lane.  q comes either
-// from an NHWC map (q_mode 0) or from a window-major [nW][64][ld] tensor (q_mode 1: OCAB's scrambled query windows);
-// k, v are NHWC maps read in place (no window_partition / Unfold copies), the output goes straight into an NHWC map.
+// One wave per (window, head).  q comes either from an NHWC map (q_mode 0) or from a window-major [nW][64][ld] tensor (q_mode 1:
+// OCAB's scrambled query windows); k, v are NHWC maps read in place (no window_partition / Unfold copies), the output goes straight
+// into an NHWC map.
 struct WinAttnParams {
     const float* q; long q_ld; int q_mode;
     const float* k; long k_ld;
@@ -555,72 +554,129 @@ struct WinAttnParams {
     float scale;
 };
 
+// Round 6: on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation, the arithmetic of the fma
+// chains it replaces), same dataflow as attn_f32_kernel (smallops.hip).  The first version ran one wave per (window, head) with
+// lane = query on the vector ALU, key / value rows as scalar loads: 18.5 TFLOP/s, 5.2 + 5.8 ms per 32-view forward at 532^2
+// (profiles/r06_bench_n1_b.json) -- two dependent scalar-load round trips and a max / vote / branch per key.  Here a wave still
+// TWO waves own one (window, head), 32 queries each: per tile of 32 keys the pair stages K (padded rows) and V in the head's LDS
+// region (zero rows for the padded positions of OCAB's 12 x 12 windows and past the last key), S^T[key][query] = K . Q^T is
+// D / 2 MFMAs per half with Q held in registers, the bias is added in the accumulator layout, the online softmax is lane-local
+// plus one exchange with lane ^ 32, and the exponentiated accumulators are the B operand of O^T = V^T . P^T.  The output rows go
+// through LDS so that every lane stores 16 contiguous bytes.
 template <int D>
-__global__ __launch_bounds__(256) void window_attn_kernel(const WinAttnParams p) {
+__global__ __launch_bounds__(512) void window_attn_kernel(const WinAttnParams p) {
+    constexpr int KP = D + 1;                              // padded K row: the A-operand read (lane -> key row) is conflict-free
+    constexpr int OP = D + 4;                              // output staging row
+    constexpr int HEAD_FLOATS = 2 * 32 * OP;               // >= 32 * KP + 32 * D: K tile + V tile, later the two halves' outputs
+    extern __shared__ __attribute__((aligned(16))) float smw[];
     const int lane = threadIdx.x & 63;
-    const int head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int head = wv >> 1, qh = wv & 1;                 // two waves per (window, head): 32 queries each, one K / V tile
+    float* Ks = smw + head * HEAD_FLOATS;
+    float* Vs = Ks + 32 * KP;
+    const int r = lane & 31, hh = lane >> 5;
     const int nwx = p.w >> 3, nwy = p.h >> 3;
     const int win = blockIdx.x;
     const int bi = win / (nwy * nwx), wrem = win - bi * (nwy * nwx);
     const int wy = wrem / nwx, wx = wrem - wy * nwx;
-    const int qy = lane >> 3, qx = lane & 7;
-    const long pix = ((long)bi * p.h + wy * 8 + qy) * p.w + wx * 8 + qx;
-    const float* qp = p.q_mode ? p.q + ((long)win * 64 + lane) * p.q_ld + head * D : p.q + pix * p.q_ld + head * D;
-    float q[D], o[D];
+    const float sl2 = p.scale * 1.44269504088896340736f;
+    // B operand of MFMA j: Q[query qh * 32 + r][2 j + hh], pre-scaled by scale * log2 e
+    float qreg[D / 2];
+    {
+        const int qi = qh * 32 + r;
+        const long pix = ((long)bi * p.h + wy * 8 + (qi >> 3)) * p.w + wx * 8 + (qi & 7);
+        const float* qp = p.q_mode ? p.q + ((long)win * 64 + qi) * p.q_ld + head * D : p.q + pix * p.q_ld + head * D;
 #pragma unroll
-    for (int c = 0; c < D / 4; ++c) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(qp + 4 * c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            q[4 * c + e] = t[e] * p.scale;
-            o[4 * c + e] = 0.f;
+        for (int c = 0; c < D / 4; ++c) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(qp + 4 * c);
+            qreg[2 * c] = (hh ? t[1] : t[0]) * sl2;
+            qreg[2 * c + 1] = (hh ? t[3] : t[2]) * sl2;
         }
     }
+    f32x16 o[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
     float m = -INFINITY, l = 0.f;
     const int nk = p.ow * p.ow;
-    const float* bias = p.bias ? p.bias + (long)head * nk * 64 + lane : nullptr;
-    for (int j = 0; j < nk; ++j) {
-        const int ky = j / p.ow, kx = j - ky * p.ow;
-        const int py = wy * 8 - p.pad + ky, px = wx * 8 - p.pad + kx;   // wave-uniform
-        const bool inb = py >= 0 && py < p.h && px >= 0 && px < p.w;
-        float sc = bias ? bias[(long)j * 64] : 0.f;
-        const long kpix = ((long)bi * p.h + (inb ? py : 0)) * p.w + (inb ? px : 0);
-        if (inb) {
-            const float* __restrict__ kr = p.k + kpix * p.k_ld + head * D;
-            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    const int lp = qh * 64 + lane;                         // lane of the head's wave pair
+    for (int t0 = 0; t0 < nk; t0 += 32) {
+        __syncthreads();                                   // (uniform: every wave of the workgroup walks the same key tiles)
 #pragma unroll
-            for (int c = 0; c < D; c += 4) {
-                d0 = fmaf(q[c], kr[c], d0);
-                d1 = fmaf(q[c + 1], kr[c + 1], d1);
-                d2 = fmaf(q[c + 2], kr[c + 2], d2);
-                d3 = fmaf(q[c + 3], kr[c + 3], d3);
+        for (int it = 0; it < D / 16; ++it) {              // 32 keys x D / 4 float4 pieces over the pair's 128 lanes
+            const int i = it * 128 + lp;
+            const int kr = i / (D / 4), c4 = i - kr * (D / 4);
+            const int j = t0 + kr;
+            const int ky = j / p.ow, kx = j - ky * p.ow;
+            const int py = wy * 8 - p.pad + ky, px = wx * 8 - p.pad + kx;
+            const bool inb = j < nk && py >= 0 && py < p.h && px >= 0 && px < p.w;
+            f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (inb) {
+                const long kpix = ((long)bi * p.h + py) * p.w + px;
+                kk = *reinterpret_cast<const f32x4*>(p.k + kpix * p.k_ld + head * D + 4 * c4);
+                vv = *reinterpret_cast<const f32x4*>(p.v + kpix * p.v_ld + head * D + 4 * c4);
             }
-            sc += (d0 + d1) + (d2 + d3);
+            Ks[kr * KP + 4 * c4] = kk[0]; Ks[kr * KP + 4 * c4 + 1] = kk[1];
+            Ks[kr * KP + 4 * c4 + 2] = kk[2]; Ks[kr * KP + 4 * c4 + 3] = kk[3];
+            *reinterpret_cast<f32x4*>(Vs + kr * D + 4 * c4) = vv;
         }
-        const float m_new = fmaxf(m, sc);
-        if (__any(m_new > m)) {   // some query's running max moved: rescale (lanes whose max did not move get corr = 1)
-            const float corr = __expf(m - m_new);
-            m = m_new;
-            l *= corr;
+        __syncthreads();
+        f32x16 s;
 #pragma unroll
-            for (int c = 0; c < D; ++c) o[c] *= corr;
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < D / 2; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[r * KP + 2 * j + hh], qreg[j], s, 0, 0, 0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = t0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            float v = s[e];
+            if (p.bias && key < nk) v += p.bias[((long)head * nk + key) * 64 + qh * 32 + r] * 1.44269504088896340736f;
+            v = key < nk ? v : -INFINITY;
+            s[e] = v;
+            mx = fmaxf(mx, v);
         }
-        const float pj = __expf(sc - m);
-        l += pj;
-        if (inb) {
-            const float* __restrict__ vr = p.v + kpix * p.v_ld + head * D;
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);     // first tile: exp2(-inf) = 0
+        m = mn;
+        float ls = 0.f;
 #pragma unroll
-            for (int c = 0; c < D; ++c) o[c] = fmaf(pj, vr[c], o[c]);
+        for (int e = 0; e < 16; ++e) {
+            s[e] = __builtin_amdgcn_exp2f(s[e] - mn);
+            ls += s[e];
+        }
+        l = l * alpha + ls;
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * D + i * 32 + r], s[e], o[i], 0, 0, 0);
+            }
         }
     }
-    const float inv = 1.0f / l;
-    float* op = p.o + pix * p.o_ld + head * D;
+    // output: O^T fragments -> this wave's half of the head's LDS region as [32 queries][D + 4] -> 16-byte row pieces to the map
+    __syncthreads();
+    float* Os = Ks + qh * (32 * OP);
+    {
+        const float inv = 1.0f / (l + __shfl_xor(l, 32, 64));
 #pragma unroll
-    for (int c = 0; c < D / 4; ++c) {
-        f32x4 t;
+        for (int i = 0; i < D / 32; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = o[4 * c + e] * inv;
-        *reinterpret_cast<f32x4*>(op + 4 * c) = t;
+            for (int e = 0; e < 16; ++e) Os[r * OP + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh] = o[i][e] * inv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < D / 8; ++it) {                   // 32 queries x D / 4 float4 pieces over 64 lanes
+        const int i = it * 64 + lane;
+        const int qr = i / (D / 4), c4 = i - qr * (D / 4);
+        const int qi = qh * 32 + qr;
+        const long pix = ((long)bi * p.h + wy * 8 + (qi >> 3)) * p.w + wx * 8 + (qi & 7);
+        *reinterpret_cast<f32x4*>(p.o + pix * p.o_ld + head * D + 4 * c4) = *reinterpret_cast<const f32x4*>(Os + qr * OP + 4 * c4);
     }
 }
 
@@ -829,11 +885,20 @@ extern "C" int iggt_window_attn_f32(const float* q, long q_ld, int q_mode, const
     WinAttnParams p;
     p.q = q; p.q_ld = q_ld; p.q_mode = q_mode; p.k = k; p.k_ld = k_ld; p.v = v; p.v_ld = v_ld; p.o = o; p.o_ld = o_ld;
     p.bias = bias; p.b = b; p.h = h; p.w = w; p.heads = heads; p.ow = ow; p.pad = pad; p.scale = scale;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16) != 0) return -2;     // 16-byte row pieces
     const long nwin = (long)b * (h / 8) * (w / 8);
+    const int lds = heads * 2 * 32 * (head_dim + 4) * 4;       // per head: K tile (padded rows) + V tile, later the output rows
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)window_attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           4 * 2 * 32 * 68 * 4);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
     if (head_dim == 32)
-        hipLaunchKernelGGL(window_attn_kernel<32>, dim3((unsigned)nwin), dim3(64 * heads), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(window_attn_kernel<32>, dim3((unsigned)nwin), dim3(128 * heads), lds, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(window_attn_kernel<64>, dim3((unsigned)nwin), dim3(64 * heads), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(window_attn_kernel<64>, dim3((unsigned)nwin), dim3(128 * heads), lds, (hipStream_t)stream, p);
     IGGT_CHECK_LAUNCH();
     return 0;
 }
