@@ -193,7 +193,8 @@ def run(pc: PackedConv, x: torch.Tensor, *, out: Optional[torch.Tensor] = None, 
         # configuration never gets here; custom heads / strides may.
         prec = 3
     w_a, w_b = pc.planes(prec)
-    with profiling.region("conv", (flops, 2 if prec == 2 else 3)):    # (algorithmic FLOPs, MFMA passes per product)
+    # (algorithmic FLOPs, MFMA passes per product, geometry): bench.py's rooflines read the first two, probes/part_branch_table.py all
+    with profiling.region("conv", (flops, 2 if prec == 2 else 3, (N, Ho, Wo, pc.Cin, pc.Cout, pc.KH, pc.stride))):
         _C.conv2d_nhwc(x, w_a, w_b, pc.bias, out, KH=pc.KH, KW=pc.KW, stride=pc.stride, pad_y=pc.pad_y,
                        pad_x=pc.pad_x, Ho=Ho, Wo=Wo, res=res, res2=res2, relu_in=relu_in, relu_res=relu_res, act=act,
                        prec=prec, Cin=pc.Cin, Cout=pc.Cout, cout_phys=pc.cout_phys, ps=pc.ps,
