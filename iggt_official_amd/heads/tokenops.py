@@ -56,3 +56,63 @@ def linear(lin: nn.Linear, x: torch.Tensor, act: int = 0, res: torch.Tensor = No
             r2 = r2.float().contiguous()
     y = co.run(pc, x2, act=act, res=r2, prec=co.PART_PREC)
     return y.view(*x.shape[:-1], Cout)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 6: the MLPs of the part head's window-attention stages on the trunk's 16-bit path.  At 32 views @ 532^2 the HAB stage
+# holds 2.96 M tokens of 128 channels: as 1 x 1 convolutions on fp32 maps its MLP read 1.5 GB and wrote a 6 GB fp32 hidden map, read
+# it again and wrote 1.5 GB -- HBM-shaped work on a kernel built for K in the thousands (~100 TFLOP/s).  Here, exactly like a trunk
+# block (layers/blocks.py): LayerNorm -> fp16, fc1 + exact GELU (LDS table) -> fp16 hidden on the 256^2 LDS-DMA GEMM, fc2 +
+# residual accumulated IN PLACE into the fp32 token matrix, fp16 weights with mean-input compensation.  Active with the two-pass
+# part branch (convops.PART_PREC == 2; IGGT_PART_CONV_PREC=3 keeps every Linear fp32-grade); part_feat stays within its budget
+# (profiles/r06_part_branch_ab.txt).
+_H16_MIN_TOKENS = 8192
+_WS = {}
+
+
+def _ws(device):
+    from ..layers.blocks import Workspace
+
+    key = str(device)          # the part branch runs on the caller's stream only (models/vggt.py)
+    if key not in _WS:
+        _WS[key] = Workspace()
+    return _WS[key]
+
+
+def mlp_h16_applicable(fc1: nn.Linear, fc2: nn.Linear, tokens: int) -> bool:
+    from .. import precision
+
+    return (co.PART_PREC == 2 and precision.operand_dtype() == torch.float16 and tokens >= _H16_MIN_TOKENS
+            and fc1.in_features % 64 == 0 and fc1.out_features % 256 == 0 and fc2.out_features % 128 == 0
+            and fc2.in_features == fc1.out_features and fc2.out_features == fc1.in_features)
+
+
+def mlp_h16_(norm: nn.LayerNorm, fc1: nn.Linear, fc2: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """x [..., C] fp32 contiguous, updated IN PLACE: x += fc2(GELU(fc1(LayerNorm(x)))) (reference window_sa.py:225,317; mlp 83-99)."""
+    from ..layers.blocks import _gemm_rows, _h16_residual, _h16_weight, compensated_bias
+
+    _need_cuda(x)
+    C, Hd = fc1.in_features, fc1.out_features
+    x2 = x.view(-1, C)
+    assert x2.is_contiguous() and x2.dtype == torch.float32
+    T = x2.shape[0]
+    cache = _PACKS.get(fc1)
+    if cache is None:
+        cache = _PACKS[fc1] = co.PackCache()
+    f16 = torch.float16
+
+    def pack():
+        w1, w2 = fc1.weight.detach().float(), fc2.weight.detach().float()
+        if not (float(torch.stack([w1.abs().amax(), w2.abs().amax()]).amax()) <= 65504.0):
+            raise _C.HipExtensionError("part-head MLP weights exceed the fp16 range: run with IGGT_PART_CONV_PREC=3")
+        return (_h16_weight(w1, f16), _h16_residual(w1, f16), fc1.bias.detach().float().contiguous(),
+                _h16_weight(w2, f16), _h16_residual(w2, f16), fc2.bias.detach().float().contiguous())
+
+    w1h, dw1, b1, w2h, dw2, b2 = cache.get("mlp_h16", (fc1.weight, fc1.bias, fc2.weight, fc2.bias), pack)
+    ws = _ws(x.device)
+    xn = ws.get("xn16", (T, C), f16, x.device)
+    _C.layernorm(x2, norm.weight.detach().float(), norm.bias.detach().float(), xn, norm.eps)
+    hid = ws.get("hid16", (T, Hd), f16, x.device)
+    _gemm_rows(xn, w1h, hid, bias=compensated_bias(ws, xn, dw1, b1), act=1)
+    _gemm_rows(hid, w2h, x2, bias=compensated_bias(ws, hid, dw2, b2), accumulate=True)
+    return x

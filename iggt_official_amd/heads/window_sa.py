@@ -71,6 +71,12 @@ class CAB(nn.Module):
 
     def forward_nhwc(self, x):
         """conv3x3 -> GELU -> conv3x3 -> channel attention (global average pool per frame), NHWC."""
+        y, g = self.forward_nhwc_gate(x)
+        return y * g[:, None, None, :]
+
+    def forward_nhwc_gate(self, x):
+        """The same as (map, per-frame channel gate): the caller folds the gate into its residual sum (one pass instead of three
+        over the 8g map)."""
         c0, c2, ca = self.cab[0], self.cab[2], self.cab[3].attention
         mid = c0.out_channels
         mid_pad = (mid + 31) // 32 * 32
@@ -81,7 +87,7 @@ class CAB(nn.Module):
         g = y.mean(dim=(1, 2))                           # AdaptiveAvgPool2d(1) over the whole frame
         g = _C.linear_f32(g, ca[1].weight.detach().flatten(1), ca[1].bias.detach(), act="relu")      # squeeze  (fp32 HIP)
         g = _C.linear_f32(g, ca[3].weight.detach().flatten(1), ca[3].bias.detach(), act="sigmoid")   # excite
-        return y * g[:, None, None, :]
+        return y, g
 
 
 class Mlp(nn.Module):
@@ -131,7 +137,7 @@ class HAB(nn.Module):
         if ws != 8 or self.attn.head_dim not in (32, 64):
             raise _C.HipExtensionError("HIP window attention is built for 8x8 windows and head dim 32 / 64")
         y = tk.layer_norm(self.norm1, x).view(b, h, w, c)
-        conv_x = self.conv_block.forward_nhwc(y.contiguous()).reshape(b, h * w, c)
+        cab, gate = self.conv_block.forward_nhwc_gate(y.contiguous())
         # per-token Linear layers commute with the window partition: qkv / proj run on the whole map and the attention
         # kernel gathers the 8x8 windows itself (no window_partition / window_reverse copies)
         qkv = tk.linear(self.attn.qkv, y)                                                  # [b, h, w, 3c]
@@ -140,8 +146,11 @@ class HAB(nn.Module):
         with profiling.region("window_attn", ("HAB 8x8 self", 4.0 * b * (h // 8) * (w // 8) * 64 * 64 * c)):
             _C.window_attn(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], o, self.attn.num_heads, self.attn.head_dim,
                            self.attn.scale)
-        att = tk.linear(self.attn.proj, o).view(b, h * w, c)
-        x = x + att + conv_x * self.conv_scale
+        # x + att in the projection's epilogue, + conv_scale * gate * cab in ONE element-wise pass (window_sa.py:221-224 as three)
+        xa = tk.linear(self.attn.proj, o.view(b, h * w, c), res=x)
+        x = torch.addcmul(xa, cab.view(b, h * w, c), (gate * self.conv_scale)[:, None, :])
+        if tk.mlp_h16_applicable(self.mlp.fc1, self.mlp.fc2, b * h * w):     # LayerNorm + MLP + residual on the 16-bit GEMM path, in place
+            return tk.mlp_h16_(self.norm2, self.mlp.fc1, self.mlp.fc2, x)
         return self.mlp(tk.layer_norm(self.norm2, x), res=x)
 
 
@@ -196,6 +205,8 @@ class OCAB(nn.Module):
         with profiling.region("window_attn", ("OCAB 8x8 x 12x12 cross", 4.0 * b * (h // 8) * (w // 8) * 64 * ow * ow * c)):
             _C.window_attn(qw, kk, vv, o, nh, d, self.scale, q_windows=True, ow=ow, pad=pad, bias=bias)
         x = tk.linear(self.proj, o.view(b, h * w, c), res=shortcut)
+        if tk.mlp_h16_applicable(self.mlp.fc1, self.mlp.fc2, b * h * w):
+            return tk.mlp_h16_(self.norm2, self.mlp.fc1, self.mlp.fc2, x)
         return self.mlp(tk.layer_norm(self.norm2, x), res=x)
 
 
