@@ -142,8 +142,9 @@ class HAB(nn.Module):
         # kernel gathers the 8x8 windows itself (no window_partition / window_reverse copies)
         qkv = tk.linear(self.attn.qkv, y)                                                  # [b, h, w, 3c]
         o = torch.empty(b, h, w, c, dtype=torch.float32, device=x.device)
-        # bench.py's part-branch leg: (kind, algorithmic FLOPs = 4 x windows x heads x 64 queries x keys x head dim)
-        with profiling.region("window_attn", ("HAB 8x8 self", 4.0 * b * (h // 8) * (w // 8) * 64 * 64 * c)):
+        # bench.py's part-branch leg: (kind, algorithmic FLOPs = 4 x windows x heads x 64 queries x keys x head dim,
+        #                                algorithmic bytes = q, k, v read + o written, fp32)
+        with profiling.region("window_attn", ("HAB 8x8 self", 4.0 * b * (h // 8) * (w // 8) * 64 * 64 * c, 16.0 * b * h * w * c)):
             _C.window_attn(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], o, self.attn.num_heads, self.attn.head_dim,
                            self.attn.scale)
         # x + att in the projection's epilogue, + conv_scale * gate * cab in ONE element-wise pass (window_sa.py:221-224 as three)
@@ -202,7 +203,9 @@ class OCAB(nn.Module):
         o = torch.empty(b, h, w, c, dtype=torch.float32, device=x.device)
         # keys / values: 12x12 windows at stride 8 read in place from the maps (zero vectors outside the image, like
         # nn.Unfold's padding); output written at the regular window positions (= window_reverse)
-        with profiling.region("window_attn", ("OCAB 8x8 x 12x12 cross", 4.0 * b * (h // 8) * (w // 8) * 64 * ow * ow * c)):
+        # (bytes: q windows + o once, k and v once per 12 x 12 window that covers them = ow^2 / 64 times)
+        with profiling.region("window_attn", ("OCAB 8x8 x 12x12 cross", 4.0 * b * (h // 8) * (w // 8) * 64 * ow * ow * c,
+                                              4.0 * b * h * w * c * (2.0 + 2.0 * ow * ow / 64.0))):
             _C.window_attn(qw, kk, vv, o, nh, d, self.scale, q_windows=True, ow=ow, pad=pad, bias=bias)
         x = tk.linear(self.proj, o.view(b, h * w, c), res=shortcut)
         if tk.mlp_h16_applicable(self.mlp.fc1, self.mlp.fc2, b * h * w):

@@ -1,4 +1,5 @@
-# Round 6, GPU batch H: final validation -- whole GPU suite, smoke, the default bench line, emulated rank, profiles.
+# Round 6, final validation on the GPU box (from the repository root): whole GPU suite, smoke, the default bench line, emulated rank,
+# kernel tables, window-attention counters, config 5 on one GPU.  Everything it writes lands in gpurun_out/; the copies under profiles/ are named r06_*.
 mkdir -p gpurun_out
 rm -f gpurun_out/parity_report.json
 python -m pytest tests -q -m gpu -p no:cacheprovider --durations=8 > gpurun_out/r06_h_suite.log 2>&1

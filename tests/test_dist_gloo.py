@@ -58,6 +58,10 @@ def _worker(rank, world, port, ret):
         assert torch.allclose(mine, full[v0 * P:v1 * P], atol=1e-6)
         cam = torch.randn(S, 2 * C)
         assert torch.equal(shard.all_gather_rows(cam[v0:v1]), cam)
+        # round 6: host decisions that change the launch sequence (a block takes the estimated-shift launches; captured graphs are
+        # invalidated) are OR-ed over the ranks, so every rank switches, warms up and re-captures in step (models/aggregator.py)
+        assert shard.agree_any([rank == 0, False, rank == 1, True], "cpu") == [1, 0, 1, 1]
+        assert shard.agree_any([False] * 48, "cpu") == [0] * 48
 
         # head-group pipelined gather: kv_local[g] = [K heads of group g | V heads of group g]; per-group attention
         # over the gathered group buffers reproduces the same rows
