@@ -142,8 +142,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloParams p
             for (int e = 0; e < 4; ++e) xv[e] = inb[it] ? fmaxf(hreg[it][e], relu_floor) : 0.f;
             hi[0] = pack_h2<FMT>(xv[0], xv[1]);       // fp16: saturating (an outlier beyond 65504 stays finite; lo takes the rest)
             hi[1] = pack_h2<FMT>(xv[2], xv[3]);
+#ifdef IGGT_CONV_NO_SPLIT   // ablation build (probes/build_alt.py conv_nosplit): what producer-written hi / lo planes could save at most
+            lo = hi;
+#else
             lo[0] = pack_h2<FMT>(xv[0] - h2_lo<FMT>(hi[0]), xv[1] - h2_hi<FMT>(hi[0]));
             lo[1] = pack_h2<FMT>(xv[2] - h2_lo<FMT>(hi[1]), xv[3] - h2_hi<FMT>(hi[1]));
+#endif
             *reinterpret_cast<u32x2*>(halo + dst_off[it]) = hi;
             *reinterpret_cast<u32x2*>(halo + HALO_PLANE + dst_off[it]) = lo;
         }

@@ -16,6 +16,8 @@ VARIANTS = {
     "hdb_stats": {"hdbscan.hip": ["-DIGGT_HDB_STATS"]},
     # round 5: the halo convolution without its epilogue (ablation: upper bound of what a cheaper epilogue could save)
     "conv_noepi": {"conv3x3_halo.hip": ["-DIGGT_CONV_NO_EPILOGUE"]},
+    # round 6: ... without the lo half of the hi / lo split of the halo (ablation: upper bound of producer-written operand planes)
+    "conv_nosplit": {"conv3x3_halo.hip": ["-DIGGT_CONV_NO_SPLIT"]},
     # estimated-shift instantiation of the static attention kernel (round 4; timed by probes/attn_est_ab.py)
     "est_default_sched": {"attention_v3_est.hip": []},
     "est_nodelta_maxilp": {"attention_v3_est.hip": ["-DIGGT_EST_NODELTA", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]},
