@@ -82,8 +82,8 @@ class CAB(nn.Module):
         mid_pad = (mid + 31) // 32 * 32
         p0 = self._pk.get(0, (c0.weight, c0.bias), lambda: co.pack_conv2d(c0))
         p2 = self._pk.get(2, (c2.weight, c2.bias), lambda: co.pack_conv2d(c2, cin_pad=mid_pad))
-        t = co.run(p0, x, act=3, ldy=mid_pad)           # GELU fused; channels [mid, mid_pad) stay zero
-        y = co.run(p2, t)
+        t = co.run(p0, x, act=3, ldy=mid_pad, prec=co.PART_PREC)   # GELU fused; channels [mid, mid_pad) stay zero
+        y = co.run(p2, t, prec=co.PART_PREC)
         g = y.mean(dim=(1, 2))                           # AdaptiveAvgPool2d(1) over the whole frame
         g = _C.linear_f32(g, ca[1].weight.detach().flatten(1), ca[1].bias.detach(), act="relu")      # squeeze  (fp32 HIP)
         g = _C.linear_f32(g, ca[3].weight.detach().flatten(1), ca[3].bias.detach(), act="sigmoid")   # excite
