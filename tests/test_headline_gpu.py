@@ -351,7 +351,7 @@ def test_config5_64_views_1036_view_permutation_equivariance():
     else.  "Nothing" up to the model's own rounding noise: the summation order inside the attention and the sampled rows of the
     compensation's column means move with the views, and a 1e-7 perturbation is enough to re-draw the roundings of the 16-bit
     operands downstream -- the two runs are two realisations of the same ~3e-4 error (measured: tokens 3.1e-4, depth 2.3e-4,
-    world_points 3.3e-4), so the gates are the parity gates (1e-3 l2, 1.5e-3 of the range).  Any index that wraps, aliases or
+    world_points 3.3e-4), so the gates are the parity gates (1e-3 l2; max 3e-3 of the range = twice the single-run gate; measured 1.2e-3).  Any index that wraps, aliases or
     depends on a view's position at this size (32-bit offsets, tile maps of the 10 962-workgroup attention grid, the 64-frame
     head passes) lands far outside them (the test checks that the permutation NOT undone does).  The per-view arithmetic at this
     grid is pinned to the reference by test_forward_2_views_1036_matches_reference, many-view arithmetic by the 32-view fixtures."""
@@ -389,4 +389,4 @@ def test_config5_64_views_1036_view_permutation_equivariance():
         assert wrong > 10 * res[k][1] and wrong > 5e-3, (k, wrong, res[k])
     report("headline/config5_permutation", {k: dict(max=v[0], l2=v[1]) for k, v in res.items()})
     for k, v in res.items():
-        assert v[1] < 1e-3 and v[0] < 1.5e-3, (k, v)
+        assert v[1] < 1e-3 and v[0] < 3e-3, (k, v)     # max: the difference of two realisations, each gated at 1.5e-3 of the range
